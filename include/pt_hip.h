@@ -1,0 +1,217 @@
+/*
+ * pt_hip.h -- C ABI of libpt_hip.so: the MI355X (gfx950) replacement for the reference's
+ * Vulkan KHR ray-tracing pipeline.
+ *
+ * The reference (clarlzx/PathTracer) has no plugin/FFI interface; its seam is the public
+ * surface of `class VulkanRaytracing` (VulkanRaytracing.h:88-117) as driven by
+ * main.cpp:272-317,433-435,1411-1412, plus the host-side scene/camera code of main.cpp that
+ * feeds it.  Every entry point below names the reference interface it replaces.
+ *
+ * Conventions: plain C types only; every int-returning function returns PT_OK (0) or a
+ * negative PT_E* code, with a human-readable message available from pt_last_error();
+ * nothing throws across the boundary; a context is used from one host thread at a time;
+ * one context per GPU.  All matrices are column-major float[16] exactly as glm::mat4.
+ * Device work is asynchronous on the context's stream unless the call returns data to the
+ * host.
+ */
+#ifndef PT_HIP_H
+#define PT_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define PT_OK 0
+#define PT_EINVAL (-1)   /* bad argument / call order */
+#define PT_EHIP (-2)     /* HIP runtime error */
+#define PT_ENOMEM (-3)
+#define PT_EIO (-4)      /* file not found / parse error (host seam) */
+#define PT_ELIMIT (-5)   /* a documented size limit was exceeded */
+
+#define PT_NO_HIT 0xFFFFFFFFu
+
+/* Byte-identical to `struct Vertex` (main.cpp:60-65, shaders/raycommon.glsl:11-17): 44 B. */
+typedef struct PtVertex
+{
+	float pos[3];
+	float normal[3];
+	float color[3];
+	float texCoord[2];
+} PtVertex;
+
+/* Byte-identical to `struct Material` (main.cpp:54-58, shaders/raycommon.glsl:19-23): 24 B. */
+typedef struct PtMaterial
+{
+	float diffuse[3];
+	float emission[3];
+} PtMaterial;
+
+/* Closest-hit record: what traceRayEXT hands to raytrace.rchit (gl_PrimitiveID +
+ * hitAttributeEXT vec2 attribs) plus the hit distance. 16 B. */
+typedef struct PtHit
+{
+	float t;
+	float u, v;     /* barycentric weights of triangle vertex 1 and 2 */
+	uint32_t prim;  /* PT_NO_HIT on a miss */
+} PtHit;
+
+typedef struct PtStats
+{
+	uint64_t rays_total;        /* closest-hit queries since the last reset (one per traceRayEXT) */
+	uint64_t rays_last_frame;
+	uint64_t paths_last_frame;  /* W*H*spp_per_frame */
+	uint64_t frames_rendered;
+	double extend_ms_total;     /* HIP-event time of the traversal kernels (only with PT_PROFILE_KERNELS) */
+	uint64_t extend_launches;
+	double shade_ms_total;
+	uint64_t shade_launches;
+	uint32_t bvh_nodes;         /* wide nodes in the acceleration structure */
+	uint32_t bvh_depth;         /* wide-node levels */
+	uint32_t bvh_tris;
+	uint32_t reserved;
+	double build_ms;            /* last pt_build_accel, device time */
+} PtStats;
+
+typedef struct pt_ctx pt_ctx;
+
+/* ---- context -------------------------------------------------------------------------- */
+
+/* VulkanRaytracing::setContext (VulkanRaytracing.cpp:9-12) + device selection
+ * (VulkanDevice.cpp:16-43).  Returns NULL on failure (pt_last_error(NULL) tells why). */
+pt_ctx *pt_create(int device_ordinal);
+
+/* VulkanRaytracing::cleanup (VulkanRaytracing.cpp:915-935). */
+void pt_destroy(pt_ctx *ctx);
+
+/* Replaces the C++ exceptions of the reference (main.cpp:1628-1636).  ctx may be NULL for
+ * errors of pt_create and of the context-free host-seam functions. */
+const char *pt_last_error(pt_ctx *ctx);
+
+/* Optional: run on a caller-owned hipStream_t (passed as void*) instead of the context's
+ * own stream; NULL restores the internal stream. */
+int pt_set_stream(pt_ctx *ctx, void *hip_stream);
+int pt_synchronize(pt_ctx *ctx);
+
+/* ---- scene + acceleration structure ---------------------------------------------------- */
+
+/* PathTracer::createModelBuffers (main.cpp:1192-1279): uploads the four scene buffers the
+ * `Model` address table points at.  n_indices must be a multiple of 3; mat_indices has
+ * n_indices/3 entries, each < n_materials.  Host pointers are copied; nothing is borrowed. */
+int pt_upload_scene(pt_ctx *ctx, const PtVertex *vertices, uint32_t n_vertices, const uint32_t *indices,
+                    uint32_t n_indices, const PtMaterial *materials, uint32_t n_materials,
+                    const uint32_t *mat_indices);
+
+#define PT_ACCEL_BVH4 0         /* LBVH (Morton + LDS radix sort) collapsed to a quantised BVH4 */
+#define PT_ACCEL_BRUTE_FORCE 1  /* no hierarchy: every ray tests every triangle (parity/debug mode) */
+
+/* VulkanRaytracing::buildBlas + buildTlas (VulkanRaytracing.cpp:147-262,448-527): what the
+ * Vulkan driver did inside vkCmdBuildAccelerationStructuresKHR.  One BLAS, one identity
+ * instance.  Blocks until the structure is built (the reference waits with vkQueueWaitIdle). */
+int pt_build_accel(pt_ctx *ctx, int flags);
+
+/* ---- frame state ---------------------------------------------------------------------- */
+
+/* PathTracer::createColorResources (main.cpp:908-931) + updateDescriptorSets + resetFrame
+ * (main.cpp:433-435): (re)allocates the RGBA32F accumulation image and the path queues. */
+int pt_resize(pt_ctx *ctx, uint32_t width, uint32_t height);
+
+/* PathTracer::updateUniformBuffer (main.cpp:1465-1480): UniformBufferObject.view/.proj.  The
+ * two inverses raytrace.rgen:44-46 recomputes per sample are hoisted here (glm algorithm). */
+int pt_set_camera(pt_ctx *ctx, const float view[16], const float proj[16]);
+
+/* The reference's compile-time constants made parameters: MAX_SAMPLES (raytrace.rgen:22,
+ * 10), MAX_RAY_DEPTH (:23, 20), tMin/tMax (:51-52, 0.001/10000), maxRTFrames
+ * (VulkanUtils.h:15, 1000; <=0 = unlimited) and an explicit `seed` that replaces the
+ * non-reproducible int(clockARB()) of raytrace.rgen:28: val1 = seed + global frame index. */
+int pt_set_params(pt_ctx *ctx, int spp_per_frame, int max_depth, float tmin, float tmax, uint32_t seed,
+                  int max_frames);
+
+/* Multi-GPU sample-stream split (no reference counterpart: the reference is single-device).
+ * The k-th pt_render_frame after a reset renders GLOBAL frame first + k*stride (seeding and
+ * the frame-0 pixel-centre rule use the global index).  Default first=0, stride=1. */
+int pt_set_frame_schedule(pt_ctx *ctx, uint32_t first, uint32_t stride);
+
+#define PT_ACCUM_MEAN 0  /* running mean, mix(old,new,1/(frame+1)): raytrace.rgen:88-95 */
+#define PT_ACCUM_SUM 1   /* raw per-frame sums (exact, order-independent multi-GPU reduce) */
+int pt_set_accum_mode(pt_ctx *ctx, int mode);
+
+/* VulkanRaytracing::raytrace (VulkanRaytracing.cpp:868-901): ++frame, dispatch W x H x 1,
+ * accumulate; a no-op once frame >= max_frames.  Asynchronous. */
+int pt_render_frame(pt_ctx *ctx);
+/* n consecutive pt_render_frame calls (convenience for the host loop, main.cpp:320-329). */
+int pt_render_frames(pt_ctx *ctx, int n);
+
+/* VulkanRaytracing::resetFrame (VulkanRaytracing.cpp:910-913): frame = -1. */
+int pt_reset_accumulation(pt_ctx *ctx);
+/* m_pcRay.frame (VulkanRaytracing.h:35-38): -1 before the first dispatch. */
+int pt_frame_index(pt_ctx *ctx);
+
+/* The image post.frag samples (shaders/post.frag:12, main.cpp:908-931): W*H*4 floats, row 0
+ * = top of the picture.  Synchronises. */
+int pt_read_image(pt_ctx *ctx, float *rgba32f);
+/* Device address of that image (for an RCCL reduce or zero-copy consumers). */
+int pt_image_device_ptr(pt_ctx *ctx, void **dev_ptr);
+/* Overwrites the accumulation image from device memory (e.g. a reduced multi-GPU result). */
+int pt_write_image_from_device(pt_ctx *ctx, const void *dev_rgba32f);
+
+/* post.frag + the B8G8R8A8_SRGB attachment (VulkanSwapchain.cpp:8): linear RGBA32F -> 8-bit
+ * sRGB RGBA, W*H*4 bytes.  Synchronises. */
+int pt_read_image_srgb8(pt_ctx *ctx, uint8_t *rgba8);
+
+#define PT_PROFILE_KERNELS 1  /* bracket traversal/shade launches with HIP events */
+int pt_set_profiling(pt_ctx *ctx, int flags);
+int pt_get_stats(pt_ctx *ctx, PtStats *out);
+int pt_reset_stats(pt_ctx *ctx);
+
+/* ---- parity / inspection entry points (test + bench support, no reference counterpart) -- */
+
+/* tea()/lcg() of shaders/random.glsl:27-51 evaluated ON THE DEVICE: out_tea[i] =
+ * tea(v0[i], v1[i]); out_lcg[i*n_steps + k] = k-th lcg output (24 bit) from state out_tea[i];
+ * out_unit[i*3..] = rnd_unit_vector drawn from state out_tea[i]. */
+int pt_debug_rng(pt_ctx *ctx, uint32_t n, const uint32_t *v0, const uint32_t *v1, uint32_t n_steps,
+                 uint32_t *out_tea, uint32_t *out_lcg, float *out_unit);
+/* Closest hits of the frame-0 primary rays (jitter = pixel centre), W*H records. */
+int pt_debug_primary_hits(pt_ctx *ctx, PtHit *hits);
+/* Closest hits for caller rays: rays = n * 6 floats (origin, direction). */
+int pt_debug_trace(pt_ctx *ctx, const float *rays, uint32_t n, float tmin, float tmax, PtHit *hits);
+/* Morton codes per primitive, the sorted primitive order, and the centroid bounds. */
+int pt_debug_morton(pt_ctx *ctx, uint32_t *codes, uint32_t *order, float cmin[3], float cmax[3]);
+/* Copies the wide BVH out: nodes (64 B each) and leaf triangles (48 B each). Pass NULL to
+ * query the counts only. */
+int pt_debug_read_bvh(pt_ctx *ctx, void *nodes, uint32_t *n_nodes, void *tris, uint32_t *n_tris);
+
+/* ---- host seam (context-free) ------------------------------------------------------------ */
+
+typedef struct PtSceneData PtSceneData;
+
+/* PathTracer::loadModel (main.cpp:1101-1190) over an OBJ/MTL parser that follows
+ * tinyobjloader v1.0.6 semantics (the reference's vendored external/tinyobjloader).
+ * Extension: faces without normals get flat geometric normals (the reference has UB there). */
+int pt_load_obj(const char *obj_path, PtSceneData **out);
+void pt_scene_free(PtSceneData *s);
+uint32_t pt_scene_n_vertices(const PtSceneData *s);
+uint32_t pt_scene_n_indices(const PtSceneData *s);
+uint32_t pt_scene_n_materials(const PtSceneData *s);
+const PtVertex *pt_scene_vertices(const PtSceneData *s);
+const uint32_t *pt_scene_indices(const PtSceneData *s);
+const PtMaterial *pt_scene_materials(const PtSceneData *s);
+const uint32_t *pt_scene_mat_indices(const PtSceneData *s);
+const char *pt_scene_warnings(const PtSceneData *s);
+
+/* glm::lookAt / glm::perspective (RH, -1..1 depth: SURVEY.md section 0) / glm::inverse as the
+ * reference's host uses them, and the fixed camera of main.cpp:1465-1480 (incl. proj[1][1]*=-1). */
+void pt_look_at(const float eye[3], const float center[3], const float up[3], float out[16]);
+void pt_perspective(float fovy_radians, float aspect, float z_near, float z_far, float out[16]);
+void pt_inverse4(const float m[16], float out[16]);
+void pt_reference_camera(uint32_t width, uint32_t height, float view[16], float proj[16]);
+
+/* Writers for the accumulation image (the reference only presents to a window). */
+int pt_write_pfm(const char *path, const float *rgba32f, uint32_t width, uint32_t height);
+int pt_write_ppm(const char *path, const uint8_t *rgba8, uint32_t width, uint32_t height);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* PT_HIP_H */

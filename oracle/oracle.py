@@ -1,0 +1,238 @@
+"""ctypes front-end of the CPU oracle (oracle/pt_oracle.c).  TEST INFRASTRUCTURE ONLY:
+imported by tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg -- never by
+the product package."""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+NONE = 0xFFFFFFFF
+
+
+class Scene(C.Structure):
+    _fields_ = [("verts", C.c_void_p), ("nVerts", C.c_uint32), ("indices", C.c_void_p), ("nIdx", C.c_uint32),
+                ("materials", C.c_void_p), ("nMat", C.c_uint32), ("matIdx", C.c_void_p)]
+
+
+class Params(C.Structure):
+    _fields_ = [("spp_per_frame", C.c_int32), ("max_depth", C.c_int32), ("tmin", C.c_float), ("tmax", C.c_float),
+                ("seed", C.c_uint32)]
+
+
+HIT_DTYPE = np.dtype([("t", np.float32), ("u", np.float32), ("v", np.float32), ("prim", np.uint32)])
+
+
+def _cpu_has_fma():
+    try:
+        with open("/proc/cpuinfo") as f:
+            for line in f:
+                if line.startswith("flags"):
+                    fl = line.split()
+                    return "fma" in fl and "avx2" in fl
+    except OSError:
+        pass
+    return False
+
+
+def build(force=False):
+    """Compile the oracle if the shared objects are missing (gcc only; no GPU needed)."""
+    if force or not os.path.exists(os.path.join(_HERE, "liboracle.so")):
+        subprocess.check_call(["make", "-C", _HERE, "all"], stdout=subprocess.DEVNULL)
+
+
+_lib = None
+
+
+def lib(portable=False):
+    global _lib
+    if portable:
+        build()
+        return _bind(C.CDLL(os.path.join(_HERE, "liboracle.so")))
+    if _lib is None:
+        build()
+        name = "liboracle_fma.so" if _cpu_has_fma() and os.path.exists(os.path.join(_HERE, "liboracle_fma.so")) \
+            else "liboracle.so"
+        _lib = _bind(C.CDLL(os.path.join(_HERE, name)))
+    return _lib
+
+
+def _bind(L):
+    u32, f32, vp = C.c_uint32, C.c_float, C.c_void_p
+    L.pto_tea.restype = u32
+    L.pto_tea.argtypes = [u32, u32]
+    L.pto_lcg.restype = u32
+    L.pto_lcg.argtypes = [C.POINTER(u32)]
+    L.pto_rnd.restype = f32
+    L.pto_rnd.argtypes = [C.POINTER(u32)]
+    L.pto_sincos_2pi.argtypes = [f32, C.POINTER(f32), C.POINTER(f32)]
+    L.pto_rnd_unit_vector.argtypes = [C.POINTER(u32), vp]
+    L.pto_lookat.argtypes = [vp, vp, vp, vp]
+    L.pto_perspective.argtypes = [f32, f32, f32, f32, vp]
+    L.pto_inverse4.argtypes = [vp, vp]
+    L.pto_reference_camera.argtypes = [u32, u32, vp, vp]
+    L.pto_camera_ray.argtypes = [vp, vp, u32, u32, u32, u32, f32, f32, vp, vp]
+    L.pto_intersect_brute.argtypes = [C.POINTER(Scene), vp, vp, f32, f32, vp]
+    L.pto_bvh_build.restype = vp
+    L.pto_bvh_build.argtypes = [C.POINTER(Scene)]
+    L.pto_bvh_free.argtypes = [vp]
+    L.pto_render_frame.restype = C.c_uint64
+    L.pto_render_frame.argtypes = [C.POINTER(Scene), vp, vp, vp, u32, u32, C.POINTER(Params), u32, u32, C.c_int, vp,
+                                   C.c_int]
+    L.pto_primary_hits.argtypes = [C.POINTER(Scene), vp, vp, vp, u32, u32, f32, f32, vp]
+    L.pto_trace_rays.argtypes = [C.POINTER(Scene), vp, vp, u32, f32, f32, vp]
+    L.pto_morton_codes.argtypes = [C.POINTER(Scene), vp, vp, vp]
+    L.pto_morton_order.argtypes = [vp, u32, vp]
+    L.pto_srgb8.argtypes = [vp, u32, vp]
+    L.pto_max_threads.restype = C.c_int
+    return L
+
+
+def _p(a):
+    return a.ctypes.data_as(C.c_void_p)
+
+
+def tea(v0, v1):
+    return int(lib().pto_tea(v0 & 0xFFFFFFFF, v1 & 0xFFFFFFFF))
+
+
+def lcg_stream(state, n):
+    """Returns (list of n lcg outputs, final state)."""
+    s = C.c_uint32(state)
+    out = [int(lib().pto_lcg(C.byref(s))) for _ in range(n)]
+    return out, int(s.value)
+
+
+def rnd_stream(state, n):
+    s = C.c_uint32(state)
+    out = np.array([lib().pto_rnd(C.byref(s)) for _ in range(n)], dtype=np.float32)
+    return out, int(s.value)
+
+
+def sincos_2pi(u):
+    s, c = C.c_float(), C.c_float()
+    lib().pto_sincos_2pi(np.float32(u), C.byref(s), C.byref(c))
+    return np.float32(s.value), np.float32(c.value)
+
+
+def rnd_unit_vector(state):
+    s = C.c_uint32(state)
+    out = np.zeros(3, dtype=np.float32)
+    lib().pto_rnd_unit_vector(C.byref(s), _p(out))
+    return out, int(s.value)
+
+
+def lookat(eye, center, up):
+    m = np.zeros(16, dtype=np.float32)
+    e, c, u = (np.ascontiguousarray(x, dtype=np.float32) for x in (eye, center, up))
+    lib().pto_lookat(_p(e), _p(c), _p(u), _p(m))
+    return m
+
+
+def perspective(fovy, aspect, near, far):
+    m = np.zeros(16, dtype=np.float32)
+    lib().pto_perspective(np.float32(fovy), np.float32(aspect), np.float32(near), np.float32(far), _p(m))
+    return m
+
+
+def inverse4(m):
+    a = np.ascontiguousarray(m, dtype=np.float32).reshape(16)
+    out = np.zeros(16, dtype=np.float32)
+    lib().pto_inverse4(_p(a), _p(out))
+    return out
+
+
+def reference_camera(W, H):
+    v = np.zeros(16, dtype=np.float32)
+    p = np.zeros(16, dtype=np.float32)
+    lib().pto_reference_camera(W, H, _p(v), _p(p))
+    return v, p
+
+
+class OracleScene:
+    """Holds the reference-layout buffers (Vertex 44 B, Material 24 B) and an optional BVH."""
+
+    def __init__(self, vertices, indices, materials, mat_indices, use_bvh=None):
+        self.vertices = np.ascontiguousarray(vertices, dtype=np.float32).reshape(-1, 11)
+        self.indices = np.ascontiguousarray(indices, dtype=np.uint32).reshape(-1)
+        self.materials = np.ascontiguousarray(materials, dtype=np.float32).reshape(-1, 6)
+        self.mat_indices = np.ascontiguousarray(mat_indices, dtype=np.uint32).reshape(-1)
+        assert self.indices.size % 3 == 0 and self.mat_indices.size == self.indices.size // 3
+        self.c = Scene(_p(self.vertices), self.vertices.shape[0], _p(self.indices), self.indices.size,
+                       _p(self.materials), self.materials.shape[0], _p(self.mat_indices))
+        if use_bvh is None:
+            use_bvh = self.indices.size // 3 > 64
+        self.bvh = lib().pto_bvh_build(C.byref(self.c)) if use_bvh else None
+
+    def __del__(self):
+        try:
+            if self.bvh:
+                lib().pto_bvh_free(self.bvh)
+        except Exception:
+            pass
+
+    @property
+    def n_tris(self):
+        return self.indices.size // 3
+
+    def primary_hits(self, view, proj, W, H, tmin=1e-3, tmax=1e4, brute=False):
+        hits = np.zeros(W * H, dtype=HIT_DTYPE)
+        v = np.ascontiguousarray(view, dtype=np.float32)
+        p = np.ascontiguousarray(proj, dtype=np.float32)
+        lib().pto_primary_hits(C.byref(self.c), None if brute else self.bvh, _p(v), _p(p), W, H, tmin, tmax, _p(hits))
+        return hits
+
+    def trace(self, rays, tmin=1e-3, tmax=1e4, brute=False):
+        r = np.ascontiguousarray(rays, dtype=np.float32).reshape(-1, 6)
+        hits = np.zeros(r.shape[0], dtype=HIT_DTYPE)
+        lib().pto_trace_rays(C.byref(self.c), None if brute else self.bvh, _p(r), r.shape[0], tmin, tmax, _p(hits))
+        return hits
+
+    def render(self, view, proj, W, H, frames, spp_per_frame=10, max_depth=20, tmin=1e-3, tmax=1e4, seed=0,
+               first_frame=0, frame_stride=1, accum_sum=False, nthreads=0, image=None, lframe0=0):
+        """Renders `frames` dispatches (global frame = first_frame + k*frame_stride) into a progressive
+        image exactly as raytrace.rgen does.  Returns (image HxWx4 f32, rays traced)."""
+        if image is None:
+            image = np.zeros((H, W, 4), dtype=np.float32)
+        v = np.ascontiguousarray(view, dtype=np.float32)
+        p = np.ascontiguousarray(proj, dtype=np.float32)
+        pp = Params(spp_per_frame, max_depth, tmin, tmax, seed)
+        rays = 0
+        for k in range(frames):
+            rays += lib().pto_render_frame(C.byref(self.c), self.bvh, _p(v), _p(p), W, H, C.byref(pp),
+                                           first_frame + k * frame_stride, lframe0 + k, int(accum_sum), _p(image),
+                                           nthreads)
+        return image, int(rays)
+
+    def morton(self):
+        n = self.n_tris
+        codes = np.zeros(n, dtype=np.uint32)
+        cmin = np.zeros(3, dtype=np.float32)
+        cmax = np.zeros(3, dtype=np.float32)
+        lib().pto_morton_codes(C.byref(self.c), _p(codes), _p(cmin), _p(cmax))
+        order = np.zeros(n, dtype=np.uint32)
+        lib().pto_morton_order(_p(codes), n, _p(order))
+        return codes, order, cmin, cmax
+
+
+def camera_ray(inv_view, inv_proj, W, H, px, py, jx=0.5, jy=0.5):
+    o = np.zeros(3, dtype=np.float32)
+    d = np.zeros(3, dtype=np.float32)
+    iv = np.ascontiguousarray(inv_view, dtype=np.float32)
+    ip = np.ascontiguousarray(inv_proj, dtype=np.float32)
+    lib().pto_camera_ray(_p(iv), _p(ip), W, H, px, py, np.float32(jx), np.float32(jy), _p(o), _p(d))
+    return o, d
+
+
+def srgb8(rgba):
+    a = np.ascontiguousarray(rgba, dtype=np.float32).reshape(-1, 4)
+    out = np.zeros((a.shape[0], 4), dtype=np.uint8)
+    lib().pto_srgb8(_p(a), a.shape[0], _p(out))
+    return out
+
+
+def max_threads():
+    return int(lib().pto_max_threads())

@@ -1,0 +1,8 @@
+"""pathtracer_amd -- MI355X-native replacement for the Vulkan KHR ray-tracing hot path of
+clarlzx/PathTracer.  The product is the C-ABI library libpt_hip.so (include/pt_hip.h); this
+package is the thin Python host mirror used by the tests and bench.py."""
+from .api import HipRaytracing, PathTracerError, Scene, load_obj, look_at, perspective, inverse4, reference_camera
+from . import scenes
+
+__all__ = ["HipRaytracing", "PathTracerError", "Scene", "load_obj", "look_at", "perspective", "inverse4",
+           "reference_camera", "scenes"]

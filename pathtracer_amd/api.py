@@ -1,0 +1,279 @@
+"""Python host mirror of the reference's seam, over the C ABI (include/pt_hip.h).
+
+`HipRaytracing` keeps the method names of `class VulkanRaytracing` (VulkanRaytracing.h:88-117)
+for the calls that survive without Vulkan -- setContext, buildBlas, buildTlas, raytrace,
+updateFrame/resetFrame, cleanup -- so that tests read like the reference's call sequence
+(main.cpp:272-317, 1411-1412).  Everything here is argument marshalling; all computation is in
+libpt_hip.so.  No function in this module has a CPU fallback.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from dataclasses import dataclass
+
+import numpy as np
+
+from . import _lib
+from ._lib import (PT_ACCEL_BRUTE_FORCE, PT_ACCEL_BVH4, PT_ACCUM_MEAN, PT_ACCUM_SUM, PT_NO_HIT, PT_PROFILE_KERNELS,
+                   PtStats)
+
+HIT_DTYPE = np.dtype([("t", np.float32), ("u", np.float32), ("v", np.float32), ("prim", np.uint32)])
+NODE_DTYPE = np.dtype([("origin", np.float32, 3), ("exps", np.uint32), ("child", np.uint32, 4),
+                       ("qlo", np.uint8, (3, 4)), ("qhi", np.uint8, (3, 4)), ("pad", np.uint32, 2)])
+TRI_DTYPE = np.dtype([("v0", np.float32, 3), ("v1", np.float32, 3), ("v2", np.float32, 3), ("prim", np.uint32),
+                      ("pad", np.uint32, 2)])
+assert HIT_DTYPE.itemsize == 16 and NODE_DTYPE.itemsize == 64 and TRI_DTYPE.itemsize == 48
+
+
+class PathTracerError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__(f"[pt error {code}] {msg}")
+        self.code = code
+
+
+def _p(a):
+    return a.ctypes.data_as(C.c_void_p)
+
+
+@dataclass
+class Scene:
+    """The four buffers of the reference's `Model` table (main.cpp:46-65, 1192-1209)."""
+    vertices: np.ndarray      # (n, 11) float32: pos3 normal3 color3 uv2   (44 B records)
+    indices: np.ndarray       # (m,) uint32
+    materials: np.ndarray     # (k, 6) float32: diffuse3 emission3         (24 B records)
+    mat_indices: np.ndarray   # (m/3,) uint32
+    warnings: str = ""
+
+    def __post_init__(self):
+        self.vertices = np.ascontiguousarray(self.vertices, dtype=np.float32).reshape(-1, 11)
+        self.indices = np.ascontiguousarray(self.indices, dtype=np.uint32).reshape(-1)
+        self.materials = np.ascontiguousarray(self.materials, dtype=np.float32).reshape(-1, 6)
+        self.mat_indices = np.ascontiguousarray(self.mat_indices, dtype=np.uint32).reshape(-1)
+
+    @property
+    def n_tris(self):
+        return self.indices.size // 3
+
+
+def load_obj(path: str) -> Scene:
+    """PathTracer::loadModel (main.cpp:1101-1190) through pt_load_obj."""
+    L = _lib.lib()
+    h = C.c_void_p()
+    rc = L.pt_load_obj(str(path).encode(), C.byref(h))
+    if rc:
+        raise PathTracerError(rc, L.pt_last_error(None).decode())
+    try:
+        nv, ni, nm = L.pt_scene_n_vertices(h), L.pt_scene_n_indices(h), L.pt_scene_n_materials(h)
+
+        def view(ptr, dtype, count):
+            if count == 0:
+                return np.zeros(0, dtype=dtype)
+            buf = (C.c_char * (count * np.dtype(dtype).itemsize)).from_address(ptr)
+            return np.frombuffer(buf, dtype=dtype, count=count).copy()
+
+        return Scene(view(L.pt_scene_vertices(h), np.float32, nv * 11).reshape(-1, 11),
+                     view(L.pt_scene_indices(h), np.uint32, ni),
+                     view(L.pt_scene_materials(h), np.float32, nm * 6).reshape(-1, 6),
+                     view(L.pt_scene_mat_indices(h), np.uint32, ni // 3),
+                     L.pt_scene_warnings(h).decode())
+    finally:
+        L.pt_scene_free(h)
+
+
+def look_at(eye, center, up):
+    e, c, u = (np.ascontiguousarray(x, dtype=np.float32) for x in (eye, center, up))
+    m = np.zeros(16, dtype=np.float32)
+    _lib.lib().pt_look_at(_p(e), _p(c), _p(u), _p(m))
+    return m
+
+
+def perspective(fovy, aspect, z_near, z_far):
+    m = np.zeros(16, dtype=np.float32)
+    _lib.lib().pt_perspective(np.float32(fovy), np.float32(aspect), np.float32(z_near), np.float32(z_far), _p(m))
+    return m
+
+
+def inverse4(m):
+    a = np.ascontiguousarray(m, dtype=np.float32).reshape(16)
+    out = np.zeros(16, dtype=np.float32)
+    _lib.lib().pt_inverse4(_p(a), _p(out))
+    return out
+
+
+def reference_camera(width, height):
+    """view, proj of main.cpp:1465-1480 (column-major float[16] each)."""
+    v = np.zeros(16, dtype=np.float32)
+    p = np.zeros(16, dtype=np.float32)
+    _lib.lib().pt_reference_camera(width, height, _p(v), _p(p))
+    return v, p
+
+
+class HipRaytracing:
+    """Drop-in for `VulkanRaytracing` on one MI355X (one context per GPU, one host thread)."""
+
+    def __init__(self, device: int = 0):
+        self._L = _lib.lib()
+        self._ctx = None
+        self.width = self.height = 0
+        self.setContext(device)
+
+    # ---- plumbing ----
+    def _check(self, rc):
+        if rc:
+            raise PathTracerError(rc, self._L.pt_last_error(self._ctx).decode())
+
+    def setContext(self, device: int):
+        """VulkanRaytracing::setContext (VulkanRaytracing.cpp:9-12)."""
+        if self._ctx:
+            self.cleanup()
+        ctx = self._L.pt_create(int(device))
+        if not ctx:
+            raise PathTracerError(-2, self._L.pt_last_error(None).decode())
+        self._ctx = C.c_void_p(ctx)
+
+    def cleanup(self):
+        """VulkanRaytracing::cleanup (VulkanRaytracing.cpp:915-935)."""
+        if self._ctx:
+            self._L.pt_destroy(self._ctx)
+            self._ctx = None
+
+    def __del__(self):
+        try:
+            self.cleanup()
+        except Exception:
+            pass
+
+    def set_stream(self, hip_stream: int | None):
+        self._check(self._L.pt_set_stream(self._ctx, C.c_void_p(hip_stream or 0)))
+
+    def synchronize(self):
+        self._check(self._L.pt_synchronize(self._ctx))
+
+    # ---- scene + acceleration structure ----
+    def uploadScene(self, scene: Scene):
+        """createModelBuffers (main.cpp:1192-1279)."""
+        s = scene
+        self._check(self._L.pt_upload_scene(self._ctx, _p(s.vertices), s.vertices.shape[0], _p(s.indices),
+                                            s.indices.size, _p(s.materials), s.materials.shape[0], _p(s.mat_indices)))
+        self._scene = s
+
+    def buildBlas(self, scene: Scene | None = None, flags: int = PT_ACCEL_BVH4):
+        """VulkanRaytracing::buildBlas (VulkanRaytracing.cpp:147-262): here the BVH is built by our own
+        kernels instead of the driver.  Includes buildTlas (single identity instance)."""
+        if scene is not None:
+            self.uploadScene(scene)
+        self._check(self._L.pt_build_accel(self._ctx, int(flags)))
+
+    def buildTlas(self):
+        """VulkanRaytracing::buildTlas (VulkanRaytracing.cpp:448-527): one identity instance -- nothing
+        left to do once the BLAS exists.  Kept so call sequences match the reference."""
+
+    # ---- frame state ----
+    def resize(self, width: int, height: int):
+        """createColorResources + updateDescriptorSets + resetFrame (main.cpp:409-436, 908-931)."""
+        self._check(self._L.pt_resize(self._ctx, width, height))
+        self.width, self.height = width, height
+
+    def setCamera(self, view, proj):
+        """updateUniformBuffer (main.cpp:1465-1480)."""
+        v = np.ascontiguousarray(view, dtype=np.float32).reshape(16)
+        p = np.ascontiguousarray(proj, dtype=np.float32).reshape(16)
+        self._check(self._L.pt_set_camera(self._ctx, _p(v), _p(p)))
+
+    def setParams(self, spp_per_frame=10, max_depth=20, tmin=1e-3, tmax=1e4, seed=0, max_frames=1000):
+        self._check(self._L.pt_set_params(self._ctx, spp_per_frame, max_depth, tmin, tmax, seed, max_frames))
+
+    def setFrameSchedule(self, first=0, stride=1):
+        self._check(self._L.pt_set_frame_schedule(self._ctx, first, stride))
+
+    def setAccumMode(self, mode):
+        self._check(self._L.pt_set_accum_mode(self._ctx, mode))
+
+    def raytrace(self, frames: int = 1):
+        """VulkanRaytracing::raytrace (VulkanRaytracing.cpp:868-901), `frames` times.  Asynchronous."""
+        self._check(self._L.pt_render_frames(self._ctx, frames))
+
+    def updateFrame(self):
+        raise NotImplementedError("updateFrame() is folded into raytrace(), as in VulkanRaytracing::raytrace")
+
+    def resetFrame(self):
+        """VulkanRaytracing::resetFrame (VulkanRaytracing.cpp:910-913)."""
+        self._check(self._L.pt_reset_accumulation(self._ctx))
+
+    @property
+    def frame(self) -> int:
+        return self._L.pt_frame_index(self._ctx)
+
+    def readImage(self) -> np.ndarray:
+        img = np.zeros((self.height, self.width, 4), dtype=np.float32)
+        self._check(self._L.pt_read_image(self._ctx, _p(img)))
+        return img
+
+    def readImageSrgb8(self) -> np.ndarray:
+        img = np.zeros((self.height, self.width, 4), dtype=np.uint8)
+        self._check(self._L.pt_read_image_srgb8(self._ctx, _p(img)))
+        return img
+
+    def imageDevicePtr(self) -> int:
+        p = C.c_void_p()
+        self._check(self._L.pt_image_device_ptr(self._ctx, C.byref(p)))
+        return p.value
+
+    def writeImageFromDevice(self, dev_ptr: int):
+        self._check(self._L.pt_write_image_from_device(self._ctx, C.c_void_p(dev_ptr)))
+
+    def setProfiling(self, flags=PT_PROFILE_KERNELS):
+        self._check(self._L.pt_set_profiling(self._ctx, flags))
+
+    def stats(self) -> PtStats:
+        st = PtStats()
+        self._check(self._L.pt_get_stats(self._ctx, C.byref(st)))
+        return st
+
+    def resetStats(self):
+        self._check(self._L.pt_reset_stats(self._ctx))
+
+    # ---- parity / inspection ----
+    def debugRng(self, v0, v1, n_steps=8):
+        v0 = np.ascontiguousarray(v0, dtype=np.uint32)
+        v1 = np.ascontiguousarray(v1, dtype=np.uint32)
+        n = v0.size
+        tea = np.zeros(n, dtype=np.uint32)
+        lcg = np.zeros((n, n_steps), dtype=np.uint32)
+        unit = np.zeros((n, 3), dtype=np.float32)
+        self._check(self._L.pt_debug_rng(self._ctx, n, _p(v0), _p(v1), n_steps, _p(tea), _p(lcg), _p(unit)))
+        return tea, lcg, unit
+
+    def debugPrimaryHits(self) -> np.ndarray:
+        hits = np.zeros(self.width * self.height, dtype=HIT_DTYPE)
+        self._check(self._L.pt_debug_primary_hits(self._ctx, _p(hits)))
+        return hits
+
+    def debugTrace(self, rays, tmin=1e-3, tmax=1e4) -> np.ndarray:
+        r = np.ascontiguousarray(rays, dtype=np.float32).reshape(-1, 6)
+        hits = np.zeros(r.shape[0], dtype=HIT_DTYPE)
+        self._check(self._L.pt_debug_trace(self._ctx, _p(r), r.shape[0], tmin, tmax, _p(hits)))
+        return hits
+
+    def debugMorton(self):
+        n = self._scene.n_tris
+        codes = np.zeros(n, dtype=np.uint32)
+        order = np.zeros(n, dtype=np.uint32)
+        cmin = np.zeros(3, dtype=np.float32)
+        cmax = np.zeros(3, dtype=np.float32)
+        self._check(self._L.pt_debug_morton(self._ctx, _p(codes), _p(order), _p(cmin), _p(cmax)))
+        return codes, order, cmin, cmax
+
+    def debugReadBvh(self):
+        nn, nt = C.c_uint32(), C.c_uint32()
+        self._check(self._L.pt_debug_read_bvh(self._ctx, None, C.byref(nn), None, C.byref(nt)))
+        nodes = np.zeros(nn.value, dtype=NODE_DTYPE)
+        tris = np.zeros(nt.value, dtype=TRI_DTYPE)
+        self._check(self._L.pt_debug_read_bvh(self._ctx, _p(nodes) if nn.value else None, C.byref(nn),
+                                              _p(tris) if nt.value else None, C.byref(nt)))
+        return nodes, tris
+
+
+__all__ = ["HipRaytracing", "PathTracerError", "Scene", "load_obj", "look_at", "perspective", "inverse4",
+           "reference_camera", "HIT_DTYPE", "NODE_DTYPE", "TRI_DTYPE", "PT_ACCEL_BVH4", "PT_ACCEL_BRUTE_FORCE",
+           "PT_ACCUM_MEAN", "PT_ACCUM_SUM", "PT_NO_HIT", "PT_PROFILE_KERNELS", "PtStats"]

@@ -1,0 +1,688 @@
+// C ABI of libpt_hip.so (include/pt_hip.h): context, scene upload, frame loop.  This is the
+// replacement for `class VulkanRaytracing` (VulkanRaytracing.h:88-117) minus everything that only
+// exists because of Vulkan (descriptor sets, pipeline, shader binding table): kernel arguments
+// take the place of descriptor sets, and the frame counter m_pcRay.frame lives in pt_ctx.
+#include <hip/hip_runtime.h>
+
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "pt_build.h"
+#include "pt_trace.h"
+
+extern const char *pt_seam_last_error();
+
+namespace
+{
+thread_local std::string g_error;
+
+// One bounce of a frame under PT_PROFILE_KERNELS: begin -> (extend) -> mid -> (shade) -> end.
+struct EventPair
+{
+	hipEvent_t begin, mid, end;
+};
+}  // namespace
+
+struct pt_ctx
+{
+	int device = 0;
+	hipStream_t ownStream = nullptr, stream = nullptr;
+	int numCUs = 256;
+	std::string error;
+
+	// scene (reference layout) + acceleration structure
+	PtVertex *dVerts = nullptr;
+	uint32_t *dIndices = nullptr, *dMatIdx = nullptr;
+	PtMaterial *dMats = nullptr;
+	uint8_t *dPrimEmissive = nullptr;
+	uint32_t nVerts = 0, nIdx = 0, nMats = 0;
+	bool haveScene = false, haveAccel = false, brute = false;
+	PtBuildOutput accel;
+	double buildMs = 0.0;
+
+	// frame state
+	uint32_t W = 0, H = 0;
+	int spp = 10, maxDepth = 20, maxFrames = 1000;
+	float tmin = 0.001f, tmax = 10000.0f;
+	uint32_t seed = 0;
+	uint32_t firstFrame = 0, frameStride = 1;
+	int accumMode = PT_ACCUM_MEAN;
+	int frame = -1;  // m_pcRay.frame
+	bool haveCamera = false;
+	PtCamera cam;
+
+	PtQueues q = {};
+	size_t queueCap = 0;  // records
+	float4 *image = nullptr;
+	PtFrameCounters *counters = nullptr;
+	unsigned long long *dStats = nullptr;  // [0] rays_total [1] rays_last_frame
+	PtLaunchCfg cfg = {};
+
+	int profiling = 0;
+	std::vector<EventPair> pending;
+	std::vector<hipEvent_t> freeEvents;
+	double extendMs = 0, shadeMs = 0;
+	uint64_t extendLaunches = 0, shadeLaunches = 0, framesRendered = 0;
+};
+
+namespace
+{
+int fail(pt_ctx *c, int code, const char *fmt, ...)
+{
+	char buf[512];
+	va_list ap;
+	va_start(ap, fmt);
+	vsnprintf(buf, sizeof(buf), fmt, ap);
+	va_end(ap);
+	if (c) c->error = buf;
+	else g_error = buf;
+	return code;
+}
+
+#define PT_HIP(c, call)                                                                             \
+	do                                                                                              \
+	{                                                                                               \
+		hipError_t e_ = (call);                                                                     \
+		if (e_ != hipSuccess) return fail(c, PT_EHIP, "%s failed: %s", #call, hipGetErrorString(e_)); \
+	} while (0)
+
+void freeQueues(pt_ctx *c)
+{
+	for (int i = 0; i < 2; ++i)
+	{
+		hipFree(c->q.rayO[i]);
+		hipFree(c->q.rayD[i]);
+		hipFree(c->q.thr[i]);
+	}
+	hipFree(c->q.hits);
+	hipFree(c->q.rad);
+	c->q = PtQueues();
+	c->queueCap = 0;
+}
+
+void freeAccel(pt_ctx *c)
+{
+	hipFree(c->accel.nodes);
+	hipFree(c->accel.tris);
+	hipFree(c->accel.codes);
+	hipFree(c->accel.order);
+	c->accel = PtBuildOutput();
+	c->haveAccel = false;
+}
+
+void freeScene(pt_ctx *c)
+{
+	hipFree(c->dVerts);
+	hipFree(c->dIndices);
+	hipFree(c->dMats);
+	hipFree(c->dMatIdx);
+	hipFree(c->dPrimEmissive);
+	c->dVerts = nullptr;
+	c->dIndices = c->dMatIdx = nullptr;
+	c->dMats = nullptr;
+	c->dPrimEmissive = nullptr;
+	c->haveScene = false;
+	freeAccel(c);
+}
+
+int ensureQueues(pt_ctx *c, size_t records)
+{
+	if (records <= c->queueCap) return PT_OK;
+	freeQueues(c);
+	const size_t bytes = records * sizeof(float4);
+	for (int i = 0; i < 2; ++i)
+	{
+		PT_HIP(c, hipMalloc(&c->q.rayO[i], bytes));
+		PT_HIP(c, hipMalloc(&c->q.rayD[i], bytes));
+		PT_HIP(c, hipMalloc(&c->q.thr[i], bytes));
+	}
+	PT_HIP(c, hipMalloc(&c->q.hits, bytes));
+	PT_HIP(c, hipMalloc(&c->q.rad, bytes));
+	c->queueCap = records;
+	return PT_OK;
+}
+
+PtSceneDev sceneDev(const pt_ctx *c)
+{
+	PtSceneDev s;
+	s.vertices = c->dVerts;
+	s.indices = c->dIndices;
+	s.materials = c->dMats;
+	s.matIndices = c->dMatIdx;
+	s.nodes = c->accel.nodes;
+	s.tris = c->accel.tris;
+	s.nTris = c->nIdx / 3;
+	s.nNodes = c->accel.nNodes;
+	return s;
+}
+
+hipEvent_t getEvent(pt_ctx *c)
+{
+	if (!c->freeEvents.empty())
+	{
+		hipEvent_t e = c->freeEvents.back();
+		c->freeEvents.pop_back();
+		return e;
+	}
+	hipEvent_t e = nullptr;
+	hipEventCreate(&e);
+	return e;
+}
+
+// Folds finished event pairs into the per-kernel-class totals.  Caller has synchronised the stream.
+void drainEvents(pt_ctx *c)
+{
+	for (EventPair &p : c->pending)
+	{
+		float ms = 0.0f;
+		if (hipEventElapsedTime(&ms, p.begin, p.mid) == hipSuccess)
+		{
+			c->extendMs += ms;
+			c->extendLaunches++;
+		}
+		if (hipEventElapsedTime(&ms, p.mid, p.end) == hipSuccess)
+		{
+			c->shadeMs += ms;
+			c->shadeLaunches++;
+		}
+		c->freeEvents.push_back(p.begin);
+		c->freeEvents.push_back(p.mid);
+		c->freeEvents.push_back(p.end);
+	}
+	c->pending.clear();
+}
+
+int checkReady(pt_ctx *c, bool needImage)
+{
+	if (!c) return fail(nullptr, PT_EINVAL, "null context");
+	if (!c->haveScene) return fail(c, PT_EINVAL, "no scene uploaded (pt_upload_scene)");
+	if (!c->haveAccel) return fail(c, PT_EINVAL, "acceleration structure not built (pt_build_accel)");
+	if (needImage && (!c->W || !c->H)) return fail(c, PT_EINVAL, "no image (pt_resize)");
+	if (needImage && !c->haveCamera) return fail(c, PT_EINVAL, "no camera (pt_set_camera)");
+	return PT_OK;
+}
+
+// Traces the rays in q.rayO[0]/q.rayD[0][0..n) into q.hits (debug entry points).
+int traceQueue0(pt_ctx *c, uint32_t n, float tmin, float tmax)
+{
+	ptLaunchFrameBegin(c->counters, n, c->stream);
+	ptLaunchExtend(sceneDev(c), c->brute, &c->counters->count[0], &c->counters->headExtend[0], c->q.rayO[0],
+	               c->q.rayD[0], c->q.hits, tmin, tmax, c->cfg, c->stream);
+	PT_HIP(c, hipGetLastError());
+	return PT_OK;
+}
+}  // namespace
+
+extern "C" const char *pt_last_error(pt_ctx *ctx)
+{
+	if (ctx) return ctx->error.c_str();
+	if (!g_error.empty()) return g_error.c_str();
+	return pt_seam_last_error();
+}
+
+extern "C" pt_ctx *pt_create(int device)
+{
+	int n = 0;
+	hipError_t e = hipGetDeviceCount(&n);
+	if (e != hipSuccess || n == 0)
+	{
+		fail(nullptr, PT_EHIP, "pt_create: no HIP device (%s)", e == hipSuccess ? "count = 0" : hipGetErrorString(e));
+		return nullptr;
+	}
+	if (device < 0 || device >= n)
+	{
+		fail(nullptr, PT_EINVAL, "pt_create: device ordinal %d out of range [0,%d)", device, n);
+		return nullptr;
+	}
+	if ((e = hipSetDevice(device)) != hipSuccess)
+	{
+		fail(nullptr, PT_EHIP, "pt_create: hipSetDevice: %s", hipGetErrorString(e));
+		return nullptr;
+	}
+	pt_ctx *c = new pt_ctx();
+	c->device = device;
+	hipDeviceProp_t prop;
+	if (hipGetDeviceProperties(&prop, device) == hipSuccess) c->numCUs = prop.multiProcessorCount;
+	bool ok = hipStreamCreateWithFlags(&c->ownStream, hipStreamNonBlocking) == hipSuccess;
+	c->stream = c->ownStream;
+	ok = ok && hipMalloc(&c->counters, sizeof(PtFrameCounters)) == hipSuccess;
+	ok = ok && hipMalloc(&c->dStats, 2 * sizeof(unsigned long long)) == hipSuccess;
+	ok = ok && hipMemset(c->dStats, 0, 2 * sizeof(unsigned long long)) == hipSuccess;
+	c->cfg.persistentBlocks = (uint32_t)c->numCUs * 4u;
+	c->cfg.spillStride = c->cfg.persistentBlocks * 256u;
+	ok = ok && hipMalloc(&c->cfg.spill, sizeof(uint32_t) * (size_t)c->cfg.spillStride * PT_SPILL_STACK) == hipSuccess;
+	if (!ok)
+	{
+		fail(nullptr, PT_EHIP, "pt_create: device allocation failed: %s", hipGetErrorString(hipGetLastError()));
+		pt_destroy(c);
+		return nullptr;
+	}
+	return c;
+}
+
+extern "C" void pt_destroy(pt_ctx *c)
+{
+	if (!c) return;
+	hipSetDevice(c->device);
+	if (c->stream) hipStreamSynchronize(c->stream);
+	drainEvents(c);
+	for (hipEvent_t e : c->freeEvents) hipEventDestroy(e);
+	freeScene(c);
+	freeQueues(c);
+	hipFree(c->image);
+	hipFree(c->counters);
+	hipFree(c->dStats);
+	hipFree(c->cfg.spill);
+	if (c->ownStream) hipStreamDestroy(c->ownStream);
+	delete c;
+}
+
+extern "C" int pt_set_stream(pt_ctx *c, void *s)
+{
+	if (!c) return fail(nullptr, PT_EINVAL, "null context");
+	PT_HIP(c, hipStreamSynchronize(c->stream));
+	drainEvents(c);
+	c->stream = s ? (hipStream_t)s : c->ownStream;
+	return PT_OK;
+}
+
+extern "C" int pt_synchronize(pt_ctx *c)
+{
+	if (!c) return fail(nullptr, PT_EINVAL, "null context");
+	PT_HIP(c, hipStreamSynchronize(c->stream));
+	drainEvents(c);
+	return PT_OK;
+}
+
+extern "C" int pt_upload_scene(pt_ctx *c, const PtVertex *v, uint32_t nV, const uint32_t *idx, uint32_t nIdx,
+                               const PtMaterial *m, uint32_t nM, const uint32_t *matIdx)
+{
+	if (!c) return fail(nullptr, PT_EINVAL, "null context");
+	if (nIdx % 3) return fail(c, PT_EINVAL, "pt_upload_scene: n_indices (%u) is not a multiple of 3", nIdx);
+	if (nIdx && (!v || !idx || !m || !matIdx || !nV || !nM))
+		return fail(c, PT_EINVAL, "pt_upload_scene: null/empty buffer with %u indices", nIdx);
+	if (nIdx / 3 > 0x0FFFFFFFu) return fail(c, PT_ELIMIT, "pt_upload_scene: more than 2^28-1 triangles");
+	const uint32_t nTris = nIdx / 3;
+	for (uint32_t i = 0; i < nIdx; ++i)
+		if (idx[i] >= nV) return fail(c, PT_EINVAL, "pt_upload_scene: index %u = %u out of range (%u vertices)", i, idx[i], nV);
+	std::vector<uint8_t> emissive(nTris ? nTris : 1);
+	for (uint32_t t = 0; t < nTris; ++t)
+	{
+		if (matIdx[t] >= nM)
+			return fail(c, PT_EINVAL, "pt_upload_scene: mat_indices[%u] = %u out of range (%u materials)", t, matIdx[t], nM);
+		const float *e = m[matIdx[t]].emission;
+		emissive[t] = ((e[0] + e[1]) + e[2] > 0.0f) ? 1 : 0;  // raytrace.rchit:56
+	}
+	PT_HIP(c, hipSetDevice(c->device));
+	PT_HIP(c, hipStreamSynchronize(c->stream));
+	freeScene(c);
+	c->nVerts = nV;
+	c->nIdx = nIdx;
+	c->nMats = nM;
+	PT_HIP(c, hipMalloc(&c->dVerts, sizeof(PtVertex) * (size_t)(nV ? nV : 1)));
+	PT_HIP(c, hipMalloc(&c->dIndices, 4 * (size_t)(nIdx ? nIdx : 1)));
+	PT_HIP(c, hipMalloc(&c->dMats, sizeof(PtMaterial) * (size_t)(nM ? nM : 1)));
+	PT_HIP(c, hipMalloc(&c->dMatIdx, 4 * (size_t)(nTris ? nTris : 1)));
+	PT_HIP(c, hipMalloc(&c->dPrimEmissive, nTris ? nTris : 1));
+	if (nIdx)
+	{
+		PT_HIP(c, hipMemcpy(c->dVerts, v, sizeof(PtVertex) * (size_t)nV, hipMemcpyHostToDevice));
+		PT_HIP(c, hipMemcpy(c->dIndices, idx, 4 * (size_t)nIdx, hipMemcpyHostToDevice));
+		PT_HIP(c, hipMemcpy(c->dMats, m, sizeof(PtMaterial) * (size_t)nM, hipMemcpyHostToDevice));
+		PT_HIP(c, hipMemcpy(c->dMatIdx, matIdx, 4 * (size_t)nTris, hipMemcpyHostToDevice));
+		PT_HIP(c, hipMemcpy(c->dPrimEmissive, emissive.data(), nTris, hipMemcpyHostToDevice));
+	}
+	c->haveScene = true;
+	return PT_OK;
+}
+
+extern "C" int pt_build_accel(pt_ctx *c, int flags)
+{
+	if (!c) return fail(nullptr, PT_EINVAL, "null context");
+	if (!c->haveScene) return fail(c, PT_EINVAL, "pt_build_accel: no scene uploaded");
+	if (flags != PT_ACCEL_BVH4 && flags != PT_ACCEL_BRUTE_FORCE) return fail(c, PT_EINVAL, "pt_build_accel: bad flags %d", flags);
+	PT_HIP(c, hipSetDevice(c->device));
+	PT_HIP(c, hipStreamSynchronize(c->stream));
+	freeAccel(c);
+	c->brute = (flags == PT_ACCEL_BRUTE_FORCE);
+	// The Morton codes / sorted order / BVH are built in both modes (the debug entry points read
+	// them); brute-force mode just does not traverse the hierarchy.
+	PtBuildInput in = { c->dVerts, c->dIndices, c->nIdx / 3 };
+	hipEvent_t a = getEvent(c), b = getEvent(c);
+	hipEventRecord(a, c->stream);
+	hipError_t e = ptBuildBvh4(in, c->accel, c->stream);
+	hipEventRecord(b, c->stream);
+	hipEventSynchronize(b);
+	float ms = 0.0f;
+	hipEventElapsedTime(&ms, a, b);
+	c->buildMs = ms;
+	c->freeEvents.push_back(a);
+	c->freeEvents.push_back(b);
+	if (e != hipSuccess) return fail(c, PT_EHIP, "pt_build_accel: BVH build failed: %s", hipGetErrorString(e));
+	if (3 * c->accel.depth + 1 > 24 + PT_SPILL_STACK)
+	{
+		uint32_t d = c->accel.depth;
+		freeAccel(c);
+		return fail(c, PT_ELIMIT, "pt_build_accel: BVH4 depth %u exceeds the traversal stack (max %d levels)", d,
+		            (24 + PT_SPILL_STACK - 1) / 3);
+	}
+	c->haveAccel = true;
+	return PT_OK;
+}
+
+extern "C" int pt_resize(pt_ctx *c, uint32_t W, uint32_t H)
+{
+	if (!c) return fail(nullptr, PT_EINVAL, "null context");
+	if (!W || !H) return fail(c, PT_EINVAL, "pt_resize: zero extent %ux%u", W, H);
+	if ((uint64_t)W * H * (uint64_t)c->spp > 0xFFFFFFF0ull)
+		return fail(c, PT_ELIMIT, "pt_resize: W*H*spp_per_frame exceeds 2^32 path ids");
+	PT_HIP(c, hipSetDevice(c->device));
+	PT_HIP(c, hipStreamSynchronize(c->stream));
+	hipFree(c->image);
+	c->image = nullptr;
+	PT_HIP(c, hipMalloc(&c->image, sizeof(float4) * (size_t)W * H));
+	PT_HIP(c, hipMemset(c->image, 0, sizeof(float4) * (size_t)W * H));
+	c->W = W;
+	c->H = H;
+	c->frame = -1;
+	return PT_OK;
+}
+
+extern "C" int pt_set_camera(pt_ctx *c, const float view[16], const float proj[16])
+{
+	if (!c || !view || !proj) return fail(c, PT_EINVAL, "pt_set_camera: null argument");
+	pt_inverse4(view, c->cam.invView);
+	pt_inverse4(proj, c->cam.invProj);
+	c->haveCamera = true;
+	return PT_OK;
+}
+
+extern "C" int pt_set_params(pt_ctx *c, int spp, int depth, float tmin, float tmax, uint32_t seed, int maxFrames)
+{
+	if (!c) return fail(nullptr, PT_EINVAL, "null context");
+	if (spp < 1) return fail(c, PT_EINVAL, "pt_set_params: spp_per_frame %d < 1", spp);
+	if (depth < 1 || depth > PT_MAX_DEPTH) return fail(c, PT_ELIMIT, "pt_set_params: max_depth %d outside [1,%d]", depth, PT_MAX_DEPTH);
+	if (!(tmin >= 0.0f) || !(tmax > tmin)) return fail(c, PT_EINVAL, "pt_set_params: need 0 <= tmin < tmax");
+	if (c->W && (uint64_t)c->W * c->H * (uint64_t)spp > 0xFFFFFFF0ull)
+		return fail(c, PT_ELIMIT, "pt_set_params: W*H*spp_per_frame exceeds 2^32 path ids");
+	c->spp = spp;
+	c->maxDepth = depth;
+	c->tmin = tmin;
+	c->tmax = tmax;
+	c->seed = seed;
+	c->maxFrames = maxFrames;
+	return PT_OK;
+}
+
+extern "C" int pt_set_frame_schedule(pt_ctx *c, uint32_t first, uint32_t stride)
+{
+	if (!c) return fail(nullptr, PT_EINVAL, "null context");
+	if (!stride) return fail(c, PT_EINVAL, "pt_set_frame_schedule: stride 0");
+	c->firstFrame = first;
+	c->frameStride = stride;
+	return PT_OK;
+}
+
+extern "C" int pt_set_accum_mode(pt_ctx *c, int mode)
+{
+	if (!c) return fail(nullptr, PT_EINVAL, "null context");
+	if (mode != PT_ACCUM_MEAN && mode != PT_ACCUM_SUM) return fail(c, PT_EINVAL, "pt_set_accum_mode: bad mode %d", mode);
+	c->accumMode = mode;
+	return PT_OK;
+}
+
+extern "C" int pt_render_frame(pt_ctx *c)
+{
+	int rc = checkReady(c, true);
+	if (rc) return rc;
+	c->frame++;  // updateFrame()
+	if (c->maxFrames > 0 && c->frame >= c->maxFrames) return PT_OK;  // "Max frames reached"
+	PT_HIP(c, hipSetDevice(c->device));
+	const uint32_t WH = c->W * c->H;
+	const size_t nPaths = (size_t)WH * c->spp;
+	rc = ensureQueues(c, nPaths);
+	if (rc) return rc;
+	const uint32_t gframe = c->firstFrame + (uint32_t)c->frame * c->frameStride;
+	hipStream_t s = c->stream;
+	PtSceneDev sc = sceneDev(c);
+	ptLaunchFrameBegin(c->counters, (uint32_t)nPaths, s);
+	ptLaunchGenerate(c->cam, c->W, c->H, (uint32_t)c->spp, c->seed + gframe, gframe == 0, c->q, s);
+	int in = 0;
+	for (int d = 0; d < c->maxDepth; ++d)
+	{
+		hipEvent_t e0 = nullptr, e1 = nullptr, e2 = nullptr;
+		if (c->profiling & PT_PROFILE_KERNELS)
+		{
+			e0 = getEvent(c);
+			e1 = getEvent(c);
+			e2 = getEvent(c);
+			hipEventRecord(e0, s);
+		}
+		ptLaunchExtend(sc, c->brute, &c->counters->count[d], &c->counters->headExtend[d], c->q.rayO[in], c->q.rayD[in],
+		               c->q.hits, c->tmin, c->tmax, c->cfg, s);
+		if (e1) hipEventRecord(e1, s);
+		ptLaunchShade(sc, c->dPrimEmissive, &c->counters->count[d], &c->counters->headShade[d], c->q, in,
+		              &c->counters->count[d + 1], d == c->maxDepth - 1, c->cfg, s);
+		if (e2)
+		{
+			hipEventRecord(e2, s);
+			c->pending.push_back({ e0, e1, e2 });
+		}
+		in ^= 1;
+	}
+	ptLaunchAccumulate(c->q, WH, (uint32_t)c->spp, c->image, (uint32_t)c->frame, c->accumMode, s);
+	ptLaunchFrameEnd(c->counters, c->maxDepth, c->dStats, s);
+	PT_HIP(c, hipGetLastError());
+	c->framesRendered++;
+	return PT_OK;
+}
+
+extern "C" int pt_render_frames(pt_ctx *c, int n)
+{
+	for (int i = 0; i < n; ++i)
+	{
+		int rc = pt_render_frame(c);
+		if (rc) return rc;
+	}
+	return PT_OK;
+}
+
+extern "C" int pt_reset_accumulation(pt_ctx *c)
+{
+	if (!c) return fail(nullptr, PT_EINVAL, "null context");
+	c->frame = -1;
+	return PT_OK;
+}
+
+extern "C" int pt_frame_index(pt_ctx *c) { return c ? c->frame : -1; }
+
+extern "C" int pt_read_image(pt_ctx *c, float *rgba)
+{
+	if (!c || !rgba) return fail(c, PT_EINVAL, "pt_read_image: null argument");
+	if (!c->image) return fail(c, PT_EINVAL, "pt_read_image: no image (pt_resize)");
+	PT_HIP(c, hipSetDevice(c->device));
+	PT_HIP(c, hipMemcpyAsync(rgba, c->image, sizeof(float4) * (size_t)c->W * c->H, hipMemcpyDeviceToHost, c->stream));
+	PT_HIP(c, hipStreamSynchronize(c->stream));
+	drainEvents(c);
+	return PT_OK;
+}
+
+extern "C" int pt_image_device_ptr(pt_ctx *c, void **p)
+{
+	if (!c || !p) return fail(c, PT_EINVAL, "pt_image_device_ptr: null argument");
+	if (!c->image) return fail(c, PT_EINVAL, "pt_image_device_ptr: no image (pt_resize)");
+	*p = c->image;
+	return PT_OK;
+}
+
+extern "C" int pt_write_image_from_device(pt_ctx *c, const void *src)
+{
+	if (!c || !src) return fail(c, PT_EINVAL, "pt_write_image_from_device: null argument");
+	if (!c->image) return fail(c, PT_EINVAL, "pt_write_image_from_device: no image (pt_resize)");
+	PT_HIP(c, hipMemcpyAsync(c->image, src, sizeof(float4) * (size_t)c->W * c->H, hipMemcpyDeviceToDevice, c->stream));
+	return PT_OK;
+}
+
+extern "C" int pt_read_image_srgb8(pt_ctx *c, uint8_t *rgba8)
+{
+	if (!c || !rgba8) return fail(c, PT_EINVAL, "pt_read_image_srgb8: null argument");
+	if (!c->image) return fail(c, PT_EINVAL, "pt_read_image_srgb8: no image (pt_resize)");
+	PT_HIP(c, hipSetDevice(c->device));
+	const uint32_t n = c->W * c->H;
+	void *tmp = nullptr;
+	PT_HIP(c, hipMalloc(&tmp, 4 * (size_t)n));
+	ptLaunchSrgb8(c->image, n, tmp, c->stream);
+	hipError_t e = hipMemcpyAsync(rgba8, tmp, 4 * (size_t)n, hipMemcpyDeviceToHost, c->stream);
+	if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+	hipFree(tmp);
+	if (e != hipSuccess) return fail(c, PT_EHIP, "pt_read_image_srgb8: %s", hipGetErrorString(e));
+	return PT_OK;
+}
+
+extern "C" int pt_set_profiling(pt_ctx *c, int flags)
+{
+	if (!c) return fail(nullptr, PT_EINVAL, "null context");
+	c->profiling = flags;
+	return PT_OK;
+}
+
+extern "C" int pt_get_stats(pt_ctx *c, PtStats *out)
+{
+	if (!c || !out) return fail(c, PT_EINVAL, "pt_get_stats: null argument");
+	PT_HIP(c, hipSetDevice(c->device));
+	unsigned long long h[2] = { 0, 0 };
+	PT_HIP(c, hipMemcpyAsync(h, c->dStats, sizeof(h), hipMemcpyDeviceToHost, c->stream));
+	PT_HIP(c, hipStreamSynchronize(c->stream));
+	drainEvents(c);
+	memset(out, 0, sizeof(*out));
+	out->rays_total = h[0];
+	out->rays_last_frame = h[1];
+	out->paths_last_frame = (uint64_t)c->W * c->H * (uint64_t)c->spp;
+	out->frames_rendered = c->framesRendered;
+	out->extend_ms_total = c->extendMs;
+	out->extend_launches = c->extendLaunches;
+	out->shade_ms_total = c->shadeMs;
+	out->shade_launches = c->shadeLaunches;
+	out->bvh_nodes = c->accel.nNodes;
+	out->bvh_depth = c->accel.depth;
+	out->bvh_tris = c->accel.nTris;
+	out->build_ms = c->buildMs;
+	return PT_OK;
+}
+
+extern "C" int pt_reset_stats(pt_ctx *c)
+{
+	if (!c) return fail(nullptr, PT_EINVAL, "null context");
+	PT_HIP(c, hipStreamSynchronize(c->stream));
+	drainEvents(c);
+	PT_HIP(c, hipMemset(c->dStats, 0, 2 * sizeof(unsigned long long)));
+	c->extendMs = c->shadeMs = 0.0;
+	c->extendLaunches = c->shadeLaunches = c->framesRendered = 0;
+	return PT_OK;
+}
+
+// ------------------------------------------------------------------- debug entry points ----
+extern "C" int pt_debug_rng(pt_ctx *c, uint32_t n, const uint32_t *v0, const uint32_t *v1, uint32_t nSteps,
+                            uint32_t *outTea, uint32_t *outLcg, float *outUnit)
+{
+	if (!c || !v0 || !v1 || !outTea || !outLcg || !outUnit) return fail(c, PT_EINVAL, "pt_debug_rng: null argument");
+	if (!n) return PT_OK;
+	PT_HIP(c, hipSetDevice(c->device));
+	uint32_t *d0 = nullptr, *d1 = nullptr, *dt = nullptr, *dl = nullptr;
+	float *du = nullptr;
+	hipError_t e = hipMalloc(&d0, 4 * (size_t)n);
+	if (e == hipSuccess) e = hipMalloc(&d1, 4 * (size_t)n);
+	if (e == hipSuccess) e = hipMalloc(&dt, 4 * (size_t)n);
+	if (e == hipSuccess) e = hipMalloc(&dl, 4 * (size_t)n * (nSteps ? nSteps : 1));
+	if (e == hipSuccess) e = hipMalloc(&du, 12 * (size_t)n);
+	if (e == hipSuccess) e = hipMemcpy(d0, v0, 4 * (size_t)n, hipMemcpyHostToDevice);
+	if (e == hipSuccess) e = hipMemcpy(d1, v1, 4 * (size_t)n, hipMemcpyHostToDevice);
+	if (e == hipSuccess)
+	{
+		ptLaunchDebugRng(n, d0, d1, nSteps, dt, dl, du, c->stream);
+		e = hipStreamSynchronize(c->stream);
+	}
+	if (e == hipSuccess) e = hipMemcpy(outTea, dt, 4 * (size_t)n, hipMemcpyDeviceToHost);
+	if (e == hipSuccess && nSteps) e = hipMemcpy(outLcg, dl, 4 * (size_t)n * nSteps, hipMemcpyDeviceToHost);
+	if (e == hipSuccess) e = hipMemcpy(outUnit, du, 12 * (size_t)n, hipMemcpyDeviceToHost);
+	hipFree(d0); hipFree(d1); hipFree(dt); hipFree(dl); hipFree(du);
+	if (e != hipSuccess) return fail(c, PT_EHIP, "pt_debug_rng: %s", hipGetErrorString(e));
+	return PT_OK;
+}
+
+extern "C" int pt_debug_primary_hits(pt_ctx *c, PtHit *hits)
+{
+	int rc = checkReady(c, true);
+	if (rc) return rc;
+	if (!hits) return fail(c, PT_EINVAL, "pt_debug_primary_hits: null argument");
+	PT_HIP(c, hipSetDevice(c->device));
+	const uint32_t WH = c->W * c->H;
+	rc = ensureQueues(c, (size_t)WH * c->spp);
+	if (rc) return rc;
+	// frame-0 rays: jitter = pixel centre (raytrace.rgen:38), one sample per pixel
+	ptLaunchGenerate(c->cam, c->W, c->H, 1, c->seed, 1, c->q, c->stream);
+	rc = traceQueue0(c, WH, c->tmin, c->tmax);
+	if (rc) return rc;
+	PT_HIP(c, hipMemcpyAsync(hits, c->q.hits, sizeof(PtHit) * (size_t)WH, hipMemcpyDeviceToHost, c->stream));
+	PT_HIP(c, hipStreamSynchronize(c->stream));
+	return PT_OK;
+}
+
+extern "C" int pt_debug_trace(pt_ctx *c, const float *rays, uint32_t n, float tmin, float tmax, PtHit *hits)
+{
+	int rc = checkReady(c, false);
+	if (rc) return rc;
+	if (!rays || !hits) return fail(c, PT_EINVAL, "pt_debug_trace: null argument");
+	if (!n) return PT_OK;
+	if (!(tmin >= 0.0f) || !(tmax > tmin)) return fail(c, PT_EINVAL, "pt_debug_trace: need 0 <= tmin < tmax");
+	PT_HIP(c, hipSetDevice(c->device));
+	rc = ensureQueues(c, n);
+	if (rc) return rc;
+	float *dr = nullptr;
+	PT_HIP(c, hipMalloc(&dr, 24 * (size_t)n));
+	hipError_t e = hipMemcpyAsync(dr, rays, 24 * (size_t)n, hipMemcpyHostToDevice, c->stream);
+	if (e == hipSuccess)
+	{
+		ptLaunchPackRays(dr, n, c->q.rayO[0], c->q.rayD[0], c->stream);
+		rc = traceQueue0(c, n, tmin, tmax);
+		if (rc == PT_OK) e = hipMemcpyAsync(hits, c->q.hits, sizeof(PtHit) * (size_t)n, hipMemcpyDeviceToHost, c->stream);
+	}
+	if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+	hipFree(dr);
+	if (rc) return rc;
+	if (e != hipSuccess) return fail(c, PT_EHIP, "pt_debug_trace: %s", hipGetErrorString(e));
+	return PT_OK;
+}
+
+extern "C" int pt_debug_morton(pt_ctx *c, uint32_t *codes, uint32_t *order, float cmin[3], float cmax[3])
+{
+	int rc = checkReady(c, false);
+	if (rc) return rc;
+	const uint32_t n = c->nIdx / 3;
+	PT_HIP(c, hipSetDevice(c->device));
+	if (codes && n) PT_HIP(c, hipMemcpy(codes, c->accel.codes, 4 * (size_t)n, hipMemcpyDeviceToHost));
+	if (order && n) PT_HIP(c, hipMemcpy(order, c->accel.order, 4 * (size_t)n, hipMemcpyDeviceToHost));
+	for (int k = 0; k < 3; ++k)
+	{
+		if (cmin) cmin[k] = c->accel.cmin[k];
+		if (cmax) cmax[k] = c->accel.cmax[k];
+	}
+	return PT_OK;
+}
+
+extern "C" int pt_debug_read_bvh(pt_ctx *c, void *nodes, uint32_t *nNodes, void *tris, uint32_t *nTris)
+{
+	int rc = checkReady(c, false);
+	if (rc) return rc;
+	PT_HIP(c, hipSetDevice(c->device));
+	if (nNodes) *nNodes = c->accel.nNodes;
+	if (nTris) *nTris = c->accel.nTris;
+	if (nodes && c->accel.nNodes)
+		PT_HIP(c, hipMemcpy(nodes, c->accel.nodes, sizeof(PtNode4) * (size_t)c->accel.nNodes, hipMemcpyDeviceToHost));
+	if (tris && c->accel.nTris)
+		PT_HIP(c, hipMemcpy(tris, c->accel.tris, sizeof(PtTri48) * (size_t)c->accel.nTris, hipMemcpyDeviceToHost));
+	return PT_OK;
+}

@@ -1,0 +1,24 @@
+// Host-callable interface of the device BVH builder (pt_bvh_build.hip).
+#pragma once
+#include "pt_device_common.h"
+
+struct PtBuildInput
+{
+	const PtVertex *vertices;  // device
+	const uint32_t *indices;   // device
+	uint32_t nTris;
+};
+
+struct PtBuildOutput
+{
+	PtNode4 *nodes = nullptr;   // device, nNodes used
+	PtTri48 *tris = nullptr;    // device, nTris, leaf order
+	uint32_t *codes = nullptr;  // device, Morton code per primitive (primitive order)
+	uint32_t *order = nullptr;  // device, primitive ids sorted by (code, id)
+	uint32_t nNodes = 0, nTris = 0, depth = 0;
+	float cmin[3] = { 0, 0, 0 }, cmax[3] = { 0, 0, 0 };
+};
+
+// Builds the quantised BVH4 on `stream`; synchronises the stream (one-time build, as the reference
+// blocks in vkQueueWaitIdle).  On success the caller owns the four device allocations in `out`.
+hipError_t ptBuildBvh4(const PtBuildInput &in, PtBuildOutput &out, hipStream_t stream);

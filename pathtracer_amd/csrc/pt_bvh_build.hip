@@ -1,0 +1,686 @@
+// Acceleration-structure build on the device: what the Vulkan driver did inside
+// vkCmdBuildAccelerationStructuresKHR for VulkanRaytracing::buildBlas/buildTlas
+// (VulkanRaytracing.cpp:147-262, 448-527).  Nothing here has a counterpart in the reference's
+// own sources; the pipeline is
+//
+//   k_tri_setup      triangle AABBs + centroid bounds (wave reduce, one atomic set per block)
+//   k_morton         30-bit Morton code per triangle (definition: DESIGN.md 5.1, oracle pto_morton_codes)
+//   radix sort       4 passes x 8 bits, LDS histogram / scan / stable LDS-ranked scatter
+//   k_lbvh_topology  Karras 2012 binary radix tree over the sorted codes
+//   k_refit          bottom-up AABB union, one agent-scope counter per internal node
+//   k_collapse_level BVH2 -> quantised BVH4 (64-byte nodes), level by level, leaf triangles
+//                    re-laid out as 48-byte records in leaf order
+#include "pt_build.h"
+
+#include <float.h>
+#include <string.h>
+
+namespace
+{
+constexpr int kBlock = 256;
+
+// ---- order-preserving float <-> int so integer atomics give float min/max ----
+__device__ __forceinline__ int floatToOrdered(float f)
+{
+	int i = __float_as_int(f);
+	return i ^ ((i >> 31) & 0x7FFFFFFF);
+}
+__host__ __device__ __forceinline__ float orderedToFloat(int i)
+{
+	int b = i ^ ((i >> 31) & 0x7FFFFFFF);
+	union
+	{
+		int i;
+		float f;
+	} u;
+	u.i = b;
+	return u.f;
+}
+
+__device__ __forceinline__ float waveMin(float v)
+{
+#pragma unroll
+	for (int o = 32; o > 0; o >>= 1) v = fminf(v, __shfl_xor(v, o));
+	return v;
+}
+__device__ __forceinline__ float waveMax(float v)
+{
+#pragma unroll
+	for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o));
+	return v;
+}
+
+// bounds[0..2] = centroid min (ordered int), [3..5] = centroid max, [6] = max |coordinate| (float bits)
+__global__ void __launch_bounds__(kBlock) k_tri_setup(const PtVertex *verts, const uint32_t *indices, uint32_t nTris,
+                                                      float4 *triLo, float4 *triHi, int *bounds)
+{
+	float cmin[3] = { FLT_MAX, FLT_MAX, FLT_MAX }, cmax[3] = { -FLT_MAX, -FLT_MAX, -FLT_MAX };
+	float amax = 0.0f;
+	for (uint32_t i = blockIdx.x * kBlock + threadIdx.x; i < nTris; i += gridDim.x * kBlock)
+	{
+		float lo[3] = { INFINITY, INFINITY, INFINITY }, hi[3] = { -INFINITY, -INFINITY, -INFINITY };
+#pragma unroll
+		for (int j = 0; j < 3; ++j)
+		{
+			const float *p = verts[indices[3 * (size_t)i + j]].pos;
+#pragma unroll
+			for (int k = 0; k < 3; ++k)
+			{
+				float c = p[k];
+				if (c < lo[k]) lo[k] = c;
+				if (c > hi[k]) hi[k] = c;
+			}
+		}
+		triLo[i] = make_float4(lo[0], lo[1], lo[2], 0.0f);
+		triHi[i] = make_float4(hi[0], hi[1], hi[2], 0.0f);
+#pragma unroll
+		for (int k = 0; k < 3; ++k)
+		{
+			float c = (lo[k] + hi[k]) * 0.5f;
+			if (c < cmin[k]) cmin[k] = c;
+			if (c > cmax[k]) cmax[k] = c;
+			amax = fmaxf(amax, fmaxf(fabsf(lo[k]), fabsf(hi[k])));
+		}
+	}
+	__shared__ float red[7][kBlock / PT_WAVE];
+	const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+	for (int k = 0; k < 3; ++k)
+	{
+		float a = waveMin(cmin[k]), b = waveMax(cmax[k]);
+		if (lane == 0)
+		{
+			red[k][wave] = a;
+			red[3 + k][wave] = b;
+		}
+	}
+	amax = waveMax(amax);
+	if (lane == 0) red[6][wave] = amax;
+	__syncthreads();
+	if (threadIdx.x < 7)
+	{
+		float v = red[threadIdx.x][0];
+		for (int w = 1; w < kBlock / PT_WAVE; ++w)
+			v = (threadIdx.x < 3) ? fminf(v, red[threadIdx.x][w]) : fmaxf(v, red[threadIdx.x][w]);
+		if (threadIdx.x < 3)
+			atomicMin(&bounds[threadIdx.x], floatToOrdered(v));
+		else if (threadIdx.x < 6)
+			atomicMax(&bounds[threadIdx.x], floatToOrdered(v));
+		else
+			atomicMax(reinterpret_cast<unsigned int *>(&bounds[6]), __float_as_uint(v));
+	}
+}
+
+__device__ __forceinline__ uint32_t expandBits10(uint32_t v)
+{
+	v = (v * 0x00010001u) & 0xFF0000FFu;
+	v = (v * 0x00000101u) & 0x0F00F00Fu;
+	v = (v * 0x00000011u) & 0xC30C30C3u;
+	v = (v * 0x00000005u) & 0x49249249u;
+	return v;
+}
+
+__global__ void __launch_bounds__(kBlock) k_morton(const float4 *triLo, const float4 *triHi, uint32_t nTris,
+                                                   const int *bounds, uint32_t *codes, uint32_t *keys, uint32_t *vals)
+{
+	uint32_t i = blockIdx.x * kBlock + threadIdx.x;
+	if (i >= nTris) return;
+	float4 lo = triLo[i], hi = triHi[i];
+	float c[3] = { (lo.x + hi.x) * 0.5f, (lo.y + hi.y) * 0.5f, (lo.z + hi.z) * 0.5f };
+	uint32_t q[3];
+#pragma unroll
+	for (int k = 0; k < 3; ++k)
+	{
+		float mn = orderedToFloat(bounds[k]), mx = orderedToFloat(bounds[3 + k]);
+		float ext = mx - mn;
+		float n = ext > 0.0f ? (c[k] - mn) / ext : 0.0f;
+		float s = n * 1024.0f;
+		if (!(s > 0.0f)) s = 0.0f;
+		if (s > 1023.0f) s = 1023.0f;
+		q[k] = (uint32_t)s;
+	}
+	uint32_t code = (expandBits10(q[0]) << 2) | (expandBits10(q[1]) << 1) | expandBits10(q[2]);
+	codes[i] = code;
+	keys[i] = code;
+	vals[i] = i;
+}
+
+// ------------------------------------------------------------------- radix sort ----
+// LSD, 8 bits per pass.  A block owns one tile of kTile consecutive keys; wave w of the block
+// owns the w-th quarter of the tile and walks it in rounds of 64 consecutive keys, so that
+// (wave, round, lane) order == input order and the scatter is stable.
+constexpr int kItems = 8;
+constexpr int kTile = kBlock * kItems;
+
+__global__ void __launch_bounds__(kBlock) k_radix_hist(const uint32_t *keys, uint32_t n, int shift, uint32_t *hist,
+                                                       uint32_t nBlocks)
+{
+	__shared__ uint32_t bins[256];
+	bins[threadIdx.x] = 0;
+	__syncthreads();
+	size_t base = (size_t)blockIdx.x * kTile;
+#pragma unroll
+	for (int r = 0; r < kItems; ++r)
+	{
+		size_t i = base + r * kBlock + threadIdx.x;
+		if (i < n) atomicAdd(&bins[(keys[i] >> shift) & 255u], 1u);
+	}
+	__syncthreads();
+	hist[(size_t)threadIdx.x * nBlocks + blockIdx.x] = bins[threadIdx.x];
+}
+
+// Exclusive scan of `len` counters, one block of 1024 threads: serial segment sums, a block scan
+// of the 1024 partials, serial write-back.
+__global__ void __launch_bounds__(1024) k_exclusive_scan(uint32_t *data, size_t len)
+{
+	__shared__ uint32_t part[1024];
+	size_t per = (len + 1023) / 1024;
+	size_t b = (size_t)threadIdx.x * per, e = b + per < len ? b + per : len;
+	uint32_t s = 0;
+	for (size_t i = b; i < e; ++i) s += data[i];
+	part[threadIdx.x] = s;
+	__syncthreads();
+	for (int o = 1; o < 1024; o <<= 1)
+	{
+		uint32_t v = threadIdx.x >= o ? part[threadIdx.x - o] : 0;
+		__syncthreads();
+		part[threadIdx.x] += v;
+		__syncthreads();
+	}
+	uint32_t run = threadIdx.x ? part[threadIdx.x - 1] : 0;
+	for (size_t i = b; i < e; ++i)
+	{
+		uint32_t v = data[i];
+		data[i] = run;
+		run += v;
+	}
+}
+
+__global__ void __launch_bounds__(kBlock) k_radix_scatter(const uint32_t *keysIn, const uint32_t *valsIn,
+                                                          uint32_t *keysOut, uint32_t *valsOut, uint32_t n, int shift,
+                                                          const uint32_t *histScanned, uint32_t nBlocks)
+{
+	constexpr int kWaves = kBlock / PT_WAVE;
+	__shared__ uint32_t waveCount[kWaves][256];
+	__shared__ uint32_t digitBase[256];
+	const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+	for (int i = threadIdx.x; i < kWaves * 256; i += kBlock) (&waveCount[0][0])[i] = 0;
+	__syncthreads();
+
+	uint32_t key[kItems], val[kItems], rank[kItems];
+	const size_t waveBase = (size_t)blockIdx.x * kTile + (size_t)wave * (kItems * PT_WAVE);
+	const unsigned long long lanesBelow = (1ull << lane) - 1ull;
+#pragma unroll
+	for (int r = 0; r < kItems; ++r)
+	{
+		size_t i = waveBase + r * PT_WAVE + lane;
+		bool valid = i < n;
+		key[r] = valid ? keysIn[i] : 0xFFFFFFFFu;
+		val[r] = valid ? valsIn[i] : 0u;
+		uint32_t digit = (key[r] >> shift) & 255u;
+		// lanes of this round holding the same digit (and the same validity)
+		unsigned long long peers = __ballot(valid);
+		if (!valid) peers = ~peers;
+#pragma unroll
+		for (int b = 0; b < 8; ++b)
+		{
+			unsigned long long m = __ballot((digit >> b) & 1u);
+			peers &= ((digit >> b) & 1u) ? m : ~m;
+		}
+		uint32_t before = waveCount[wave][digit];
+		rank[r] = before + __popcll(peers & lanesBelow);
+		// the lowest peer lane publishes the new running count for this digit
+		if (valid && (peers & lanesBelow) == 0) waveCount[wave][digit] = before + __popcll(peers);
+	}
+	__syncthreads();
+	{
+		// exclusive scan across the waves of the block for digit = threadIdx.x
+		uint32_t run = 0;
+		for (int w = 0; w < kWaves; ++w)
+		{
+			uint32_t c = waveCount[w][threadIdx.x];
+			waveCount[w][threadIdx.x] = run;
+			run += c;
+		}
+		digitBase[threadIdx.x] = histScanned[(size_t)threadIdx.x * nBlocks + blockIdx.x];
+	}
+	__syncthreads();
+#pragma unroll
+	for (int r = 0; r < kItems; ++r)
+	{
+		size_t i = waveBase + r * PT_WAVE + lane;
+		if (i < n)
+		{
+			uint32_t digit = (key[r] >> shift) & 255u;
+			uint32_t dst = digitBase[digit] + waveCount[wave][digit] + rank[r];
+			keysOut[dst] = key[r];
+			valsOut[dst] = val[r];
+		}
+	}
+}
+
+// ----------------------------------------------------------------- LBVH topology ----
+// BVH2 node numbering: internal nodes 0 .. n-2, leaf for sorted position k is (n-1) + k.
+__device__ __forceinline__ int lbvhDelta(const uint32_t *keys, int n, int i, int j)
+{
+	if (j < 0 || j >= n) return -1;
+	uint32_t a = keys[i], b = keys[j];
+	if (a == b) return 32 + __clz((uint32_t)i ^ (uint32_t)j);
+	return __clz(a ^ b);
+}
+
+__global__ void __launch_bounds__(kBlock) k_lbvh_topology(const uint32_t *keys, int n, int2 *children, int *parent,
+                                                          int2 *range)
+{
+	int i = blockIdx.x * kBlock + threadIdx.x;
+	if (i >= n - 1) return;
+	int d = (lbvhDelta(keys, n, i, i + 1) - lbvhDelta(keys, n, i, i - 1)) >= 0 ? 1 : -1;
+	int dmin = lbvhDelta(keys, n, i, i - d);
+	int lmax = 2;
+	while (lbvhDelta(keys, n, i, i + lmax * d) > dmin) lmax <<= 1;
+	int l = 0;
+	for (int t = lmax >> 1; t >= 1; t >>= 1)
+		if (lbvhDelta(keys, n, i, i + (l + t) * d) > dmin) l += t;
+	int j = i + l * d;
+	int dnode = lbvhDelta(keys, n, i, j);
+	int s = 0;
+	int t = l;
+	do
+	{
+		t = (t + 1) >> 1;
+		if (lbvhDelta(keys, n, i, i + (s + t) * d) > dnode) s += t;
+	} while (t > 1);
+	int gamma = i + s * d + (d < 0 ? d : 0);
+	int first = i < j ? i : j, last = i < j ? j : i;
+	int left = (first == gamma) ? (n - 1) + gamma : gamma;
+	int right = (last == gamma + 1) ? (n - 1) + gamma + 1 : gamma + 1;
+	children[i] = make_int2(left, right);
+	range[i] = make_int2(first, last);
+	parent[left] = i;
+	parent[right] = i;
+	if (i == 0) parent[0] = -1;
+}
+
+// ------------------------------------------------------------------------- refit ----
+// boxes: 2 float4 per BVH2 node: (lo.xyz, -) (hi.xyz, -).  Boxes cross CUs inside this launch,
+// so every box store/load is an agent-scope (sc1) access and the arrival counter is an
+// agent-scope atomic issued after the storing lane's vmcnt has drained.
+__device__ __forceinline__ void storeBox(float *dst, const float lo[3], const float hi[3])
+{
+#pragma unroll
+	for (int k = 0; k < 3; ++k)
+	{
+		__hip_atomic_store(dst + k, lo[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+		__hip_atomic_store(dst + 4 + k, hi[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+	}
+}
+__device__ __forceinline__ void loadBox(const float *src, float lo[3], float hi[3])
+{
+#pragma unroll
+	for (int k = 0; k < 3; ++k)
+	{
+		lo[k] = __hip_atomic_load(src + k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+		hi[k] = __hip_atomic_load(src + 4 + k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+	}
+}
+
+__global__ void __launch_bounds__(kBlock) k_refit(const float4 *triLo, const float4 *triHi, const uint32_t *sortedPrim,
+                                                  int n, const int2 *children, const int *parent, const int *bounds,
+                                                  float *boxes, unsigned int *arrive)
+{
+	int k = blockIdx.x * kBlock + threadIdx.x;
+	if (k >= n) return;
+	const float pad = __uint_as_float((unsigned int)bounds[6]) * (1.0f / 262144.0f);  // 2^-18 * max|coord|
+	uint32_t prim = sortedPrim[k];
+	float4 l4 = triLo[prim], h4 = triHi[prim];
+	float lo[3] = { l4.x - pad, l4.y - pad, l4.z - pad }, hi[3] = { h4.x + pad, h4.y + pad, h4.z + pad };
+	int node = (n - 1) + k;
+	storeBox(boxes + 8 * (size_t)node, lo, hi);
+	int p = parent[node];
+	while (p >= 0)
+	{
+		asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+		unsigned int old = __hip_atomic_fetch_add(&arrive[p], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+		if (old == 0) return;  // the sibling subtree finishes this node
+		int2 ch = children[p];
+		float lo2[3], hi2[3];
+		loadBox(boxes + 8 * (size_t)ch.x, lo, hi);
+		loadBox(boxes + 8 * (size_t)ch.y, lo2, hi2);
+#pragma unroll
+		for (int a = 0; a < 3; ++a)
+		{
+			lo[a] = fminf(lo[a], lo2[a]);
+			hi[a] = fmaxf(hi[a], hi2[a]);
+		}
+		storeBox(boxes + 8 * (size_t)p, lo, hi);
+		p = parent[p];
+	}
+}
+
+// ---------------------------------------------------------------------- collapse ----
+struct CollapseTask
+{
+	int bvh2;     // BVH2 node this wide node is rooted at
+	uint32_t out; // wide-node slot to write
+};
+
+__device__ __forceinline__ void nodeRange(int node, int n, const int2 *range, int &first, int &last)
+{
+	if (node >= n - 1)
+	{
+		first = last = node - (n - 1);
+	}
+	else
+	{
+		int2 r = range[node];
+		first = r.x;
+		last = r.y;
+	}
+}
+
+__device__ __forceinline__ float halfArea(const float *box)
+{
+	float dx = box[4] - box[0], dy = box[5] - box[1], dz = box[6] - box[2];
+	return (dx * dy + dy * dz) + dz * dx;
+}
+
+__global__ void __launch_bounds__(kBlock)
+    k_collapse_level(const CollapseTask *tasksIn, uint32_t nIn, CollapseTask *tasksOut, uint32_t *nOut, int n,
+                     const int2 *children, const int2 *range, const float *boxes, const uint32_t *sortedPrim,
+                     const PtVertex *verts, const uint32_t *indices, PtNode4 *nodes, uint32_t *nodeCount,
+                     PtTri48 *tris, uint32_t *triCount)
+{
+	uint32_t ti = blockIdx.x * kBlock + threadIdx.x;
+	if (ti >= nIn) return;
+	CollapseTask task = tasksIn[ti];
+
+	int slot[4];
+	int nSlots = 0;
+	{
+		int f, l;
+		nodeRange(task.bvh2, n, range, f, l);
+		if (l - f + 1 <= PT_LEAF_MAX)
+			slot[nSlots++] = task.bvh2;  // whole subtree is one leaf child
+		else
+		{
+			int2 ch = children[task.bvh2];
+			slot[0] = ch.x;
+			slot[1] = ch.y;
+			nSlots = 2;
+			while (nSlots < 4)
+			{
+				int best = -1;
+				float bestArea = -1.0f;
+				for (int s = 0; s < nSlots; ++s)
+				{
+					int f2, l2;
+					nodeRange(slot[s], n, range, f2, l2);
+					if (l2 - f2 + 1 <= PT_LEAF_MAX) continue;  // stays a leaf child
+					float a = halfArea(boxes + 8 * (size_t)slot[s]);
+					if (a > bestArea)
+					{
+						bestArea = a;
+						best = s;
+					}
+				}
+				if (best < 0) break;
+				int2 ch2 = children[slot[best]];
+				slot[best] = ch2.x;
+				slot[nSlots++] = ch2.y;
+			}
+		}
+	}
+
+	// node frame: origin = min corner, power-of-two scale per axis covering the extent in 255 steps
+	float org[3] = { INFINITY, INFINITY, INFINITY }, top[3] = { -INFINITY, -INFINITY, -INFINITY };
+	for (int s = 0; s < nSlots; ++s)
+	{
+		const float *b = boxes + 8 * (size_t)slot[s];
+#pragma unroll
+		for (int a = 0; a < 3; ++a)
+		{
+			org[a] = fminf(org[a], b[a]);
+			top[a] = fmaxf(top[a], b[4 + a]);
+		}
+	}
+	uint32_t expBits[3];
+	float scale[3];
+#pragma unroll
+	for (int a = 0; a < 3; ++a)
+	{
+		float ext = top[a] - org[a];
+		int e = 1;
+		if (ext > 0.0f)
+		{
+			int ex;
+			float m = frexpf(ext / 255.0f, &ex);  // ext/255 = m * 2^ex, m in [0.5,1)
+			e = (m == 0.5f ? ex - 1 : ex) + 127;
+		}
+		if (e < 1) e = 1;
+		if (e > 254) e = 254;
+		float sc = __uint_as_float((uint32_t)e << 23);
+		while (e < 254 && !(__builtin_fmaf(255.0f, sc, org[a]) >= top[a]))
+		{
+			++e;
+			sc = __uint_as_float((uint32_t)e << 23);
+		}
+		expBits[a] = (uint32_t)e;
+		scale[a] = sc;
+	}
+
+	PtNode4 node;
+	node.origin[0] = org[0];
+	node.origin[1] = org[1];
+	node.origin[2] = org[2];
+	node.exps = expBits[0] | (expBits[1] << 8) | (expBits[2] << 16);
+	node.pad[0] = node.pad[1] = 0;
+	for (int a = 0; a < 3; ++a)
+	{
+		node.qlo[a] = 0xFFFFFFFFu;  // empty slots: lo = 255, hi = 0
+		node.qhi[a] = 0u;
+	}
+	for (int c = 0; c < 4; ++c) node.child[c] = PT_EMPTY_CHILD;
+
+	for (int s = 0; s < nSlots; ++s)
+	{
+		const float *b = boxes + 8 * (size_t)slot[s];
+#pragma unroll
+		for (int a = 0; a < 3; ++a)
+		{
+			float ql = floorf((b[a] - org[a]) / scale[a]);
+			ql = fminf(fmaxf(ql, 0.0f), 255.0f);
+			while (ql > 0.0f && __builtin_fmaf(ql, scale[a], org[a]) > b[a]) ql -= 1.0f;
+			float qh = ceilf((b[4 + a] - org[a]) / scale[a]);
+			qh = fminf(fmaxf(qh, 0.0f), 255.0f);
+			while (qh < 255.0f && __builtin_fmaf(qh, scale[a], org[a]) < b[4 + a]) qh += 1.0f;
+			node.qlo[a] = (node.qlo[a] & ~(0xFFu << (8 * s))) | ((uint32_t)ql << (8 * s));
+			node.qhi[a] = (node.qhi[a] & ~(0xFFu << (8 * s))) | ((uint32_t)qh << (8 * s));
+		}
+		int f, l;
+		nodeRange(slot[s], n, range, f, l);
+		int cnt = l - f + 1;
+		if (cnt <= PT_LEAF_MAX)
+		{
+			uint32_t base = atomicAdd(triCount, (uint32_t)cnt);
+			for (int t = 0; t < cnt; ++t)
+			{
+				uint32_t prim = sortedPrim[f + t];
+				PtTri48 tr;
+				const float *p0 = verts[indices[3 * (size_t)prim + 0]].pos;
+				const float *p1 = verts[indices[3 * (size_t)prim + 1]].pos;
+				const float *p2 = verts[indices[3 * (size_t)prim + 2]].pos;
+				for (int a = 0; a < 3; ++a)
+				{
+					tr.v0[a] = p0[a];
+					tr.v1[a] = p1[a];
+					tr.v2[a] = p2[a];
+				}
+				tr.prim = prim;
+				tr.pad[0] = tr.pad[1] = 0;
+				tris[base + t] = tr;
+			}
+			node.child[s] = PT_LEAF_FLAG | ((uint32_t)(cnt - 1) << 28) | base;
+		}
+		else
+		{
+			uint32_t idx = atomicAdd(nodeCount, 1u);
+			node.child[s] = idx;
+			uint32_t q = atomicAdd(nOut, 1u);
+			tasksOut[q].bvh2 = slot[s];
+			tasksOut[q].out = idx;
+		}
+	}
+	nodes[task.out] = node;
+}
+
+__global__ void k_init_bounds(int *bounds)
+{
+	if (threadIdx.x < 3) bounds[threadIdx.x] = 0x7FFFFFFF;
+	else if (threadIdx.x < 6) bounds[threadIdx.x] = (int)0x80000000;
+	else if (threadIdx.x == 6) bounds[6] = 0;
+}
+}  // namespace
+
+#define HIPCHK(x)                    \
+	do                               \
+	{                                \
+		hipError_t e_ = (x);         \
+		if (e_ != hipSuccess) return e_; \
+	} while (0)
+
+static inline uint32_t divUp(size_t a, size_t b) { return (uint32_t)((a + b - 1) / b); }
+
+hipError_t ptBuildBvh4(const PtBuildInput &in, PtBuildOutput &out, hipStream_t stream)
+{
+	const uint32_t n = in.nTris;
+	out = PtBuildOutput();
+	if (n == 0) return hipSuccess;
+	if (n > 0x0FFFFFFFu) return hipErrorInvalidValue;
+
+	// ---- scratch (freed on exit) ----
+	float4 *triLo = nullptr, *triHi = nullptr;
+	int *bounds = nullptr;
+	uint32_t *keysA = nullptr, *keysB = nullptr, *valsA = nullptr, *valsB = nullptr, *hist = nullptr;
+	int2 *children = nullptr, *range = nullptr;
+	int *parent = nullptr;
+	float *boxes = nullptr;
+	unsigned int *arrive = nullptr;
+	CollapseTask *taskA = nullptr, *taskB = nullptr;
+	uint32_t *counters = nullptr;  // [0]=nodeCount [1]=triCount [2]=queue count
+	const uint32_t nSortBlocks = divUp(n, kTile);
+	const size_t histLen = (size_t)256 * nSortBlocks;
+	const size_t nNodes2 = 2 * (size_t)n - 1;
+	hipError_t err = hipSuccess;
+#define TRY(x)                      \
+	if (err == hipSuccess) err = (x)
+	TRY(hipMalloc(&triLo, sizeof(float4) * n));
+	TRY(hipMalloc(&triHi, sizeof(float4) * n));
+	TRY(hipMalloc(&bounds, sizeof(int) * 8));
+	TRY(hipMalloc(&keysA, 4 * (size_t)n));
+	TRY(hipMalloc(&keysB, 4 * (size_t)n));
+	TRY(hipMalloc(&valsA, 4 * (size_t)n));
+	TRY(hipMalloc(&valsB, 4 * (size_t)n));
+	TRY(hipMalloc(&hist, 4 * histLen));
+	TRY(hipMalloc(&children, sizeof(int2) * n));
+	TRY(hipMalloc(&range, sizeof(int2) * n));
+	TRY(hipMalloc(&parent, sizeof(int) * nNodes2));
+	TRY(hipMalloc(&boxes, sizeof(float) * 8 * nNodes2));
+	TRY(hipMalloc(&arrive, sizeof(unsigned int) * n));
+	TRY(hipMalloc(&taskA, sizeof(CollapseTask) * n));
+	TRY(hipMalloc(&taskB, sizeof(CollapseTask) * n));
+	TRY(hipMalloc(&counters, sizeof(uint32_t) * 4));
+	// outputs
+	PtNode4 *nodes = nullptr;
+	PtTri48 *tris = nullptr;
+	uint32_t *codes = nullptr, *order = nullptr;
+	float *cbounds = nullptr;
+	TRY(hipMalloc(&nodes, sizeof(PtNode4) * (size_t)n));  // a wide node has >= 2 children unless it is the root
+	TRY(hipMalloc(&tris, sizeof(PtTri48) * (size_t)n));
+	TRY(hipMalloc(&codes, 4 * (size_t)n));
+	TRY(hipMalloc(&order, 4 * (size_t)n));
+
+	uint32_t depth = 0, nodeCount = 0;
+	if (err == hipSuccess)
+	{
+		const uint32_t gridTris = divUp(n, kBlock);
+		k_init_bounds<<<1, 64, 0, stream>>>(bounds);
+		k_tri_setup<<<gridTris < 2048 ? gridTris : 2048, kBlock, 0, stream>>>(in.vertices, in.indices, n, triLo, triHi,
+		                                                                       bounds);
+		k_morton<<<gridTris, kBlock, 0, stream>>>(triLo, triHi, n, bounds, codes, keysA, valsA);
+		uint32_t *kin = keysA, *kout = keysB, *vin = valsA, *vout = valsB;
+		for (int shift = 0; shift < 32; shift += 8)
+		{
+			k_radix_hist<<<nSortBlocks, kBlock, 0, stream>>>(kin, n, shift, hist, nSortBlocks);
+			k_exclusive_scan<<<1, 1024, 0, stream>>>(hist, histLen);
+			k_radix_scatter<<<nSortBlocks, kBlock, 0, stream>>>(kin, vin, kout, vout, n, shift, hist, nSortBlocks);
+			uint32_t *t = kin;
+			kin = kout;
+			kout = t;
+			t = vin;
+			vin = vout;
+			vout = t;
+		}
+		// after an even number of passes the sorted data is back in (keysA, valsA)
+		err = hipMemcpyAsync(order, vin, 4 * (size_t)n, hipMemcpyDeviceToDevice, stream);
+		TRY(hipMemsetAsync(arrive, 0, sizeof(unsigned int) * n, stream));
+		if (err == hipSuccess)
+		{
+			if (n > 1) k_lbvh_topology<<<divUp(n - 1, kBlock), kBlock, 0, stream>>>(kin, (int)n, children, parent, range);
+			else err = hipMemsetAsync(parent, 0xFF, sizeof(int), stream);  // single leaf: parent = -1
+			k_refit<<<gridTris, kBlock, 0, stream>>>(triLo, triHi, vin, (int)n, children, parent, bounds, boxes, arrive);
+		}
+		// collapse, level by level (host reads the queue length between levels; one-time build)
+		uint32_t init[4] = { 1u, 0u, 0u, 0u };
+		TRY(hipMemcpyAsync(counters, init, sizeof(init), hipMemcpyHostToDevice, stream));
+		CollapseTask root = { 0, 0u };  // BVH2 root is internal node 0 (or the only leaf, index 0, when n == 1)
+		TRY(hipMemcpyAsync(taskA, &root, sizeof(root), hipMemcpyHostToDevice, stream));
+		uint32_t nIn = 1;
+		CollapseTask *tin = taskA, *tout = taskB;
+		while (err == hipSuccess && nIn > 0)
+		{
+			++depth;
+			k_collapse_level<<<divUp(nIn, kBlock), kBlock, 0, stream>>>(tin, nIn, tout, counters + 2, (int)n, children,
+			                                                          range, boxes, vin, in.vertices, in.indices, nodes,
+			                                                          counters, tris, counters + 1);
+			uint32_t h[4];
+			err = hipMemcpyAsync(h, counters, sizeof(h), hipMemcpyDeviceToHost, stream);
+			TRY(hipStreamSynchronize(stream));
+			if (err != hipSuccess) break;
+			nIn = h[2];
+			nodeCount = h[0];
+			if (h[1] > n || h[0] > n) { err = hipErrorAssert; break; }
+			TRY(hipMemsetAsync(counters + 2, 0, sizeof(uint32_t), stream));
+			CollapseTask *t = tin;
+			tin = tout;
+			tout = t;
+		}
+		TRY(hipGetLastError());
+	}
+	if (err == hipSuccess)
+	{
+		int hb[8];
+		err = hipMemcpy(hb, bounds, sizeof(int) * 7, hipMemcpyDeviceToHost);
+		for (int k = 0; k < 3; ++k)
+		{
+			out.cmin[k] = orderedToFloat(hb[k]);
+			out.cmax[k] = orderedToFloat(hb[3 + k]);
+		}
+	}
+#undef TRY
+	hipFree(triLo); hipFree(triHi); hipFree(bounds); hipFree(keysA); hipFree(keysB); hipFree(valsA); hipFree(valsB);
+	hipFree(hist); hipFree(children); hipFree(range); hipFree(parent); hipFree(boxes); hipFree(arrive);
+	hipFree(taskA); hipFree(taskB); hipFree(counters);
+	if (err != hipSuccess)
+	{
+		hipFree(nodes); hipFree(tris); hipFree(codes); hipFree(order);
+		return err;
+	}
+	out.nodes = nodes;
+	out.tris = tris;
+	out.codes = codes;
+	out.order = order;
+	out.nNodes = nodeCount;
+	out.nTris = n;
+	out.depth = depth;
+	return hipSuccess;
+}

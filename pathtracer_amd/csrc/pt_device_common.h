@@ -1,0 +1,278 @@
+// Device-side building blocks shared by the HIP kernels (gfx950 only).
+//
+// ARITHMETIC CONTRACT.  Everything here is compiled with -ffp-contract=off: IEEE binary32,
+// round-to-nearest-even, correctly rounded '/' and sqrt (hipcc default
+// -fhip-fp32-correctly-rounded-divide-sqrt), fp32 denormals kept, and a fused multiply-add
+// ONLY where __builtin_fmaf is written out.  The expression order of every function that
+// feeds a result (RNG, camera ray, triangle test, shading) is part of the specification in
+// DESIGN.md section 4, which the CPU oracle implements independently; the two agree bit for bit.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/pt_hip.h"
+
+#define PT_WAVE 64
+
+struct float3x
+{
+	float x, y, z;
+};
+
+// ------------------------------------------------------------------------------ RNG ----
+// shaders/random.glsl:27-41
+__device__ __forceinline__ uint32_t pt_tea(uint32_t val0, uint32_t val1)
+{
+	uint32_t v0 = val0, v1 = val1, s0 = 0;
+#pragma unroll
+	for (int n = 0; n < 16; n++)
+	{
+		s0 += 0x9e3779b9u;
+		v0 += ((v1 << 4) + 0xa341316cu) ^ (v1 + s0) ^ ((v1 >> 5) + 0xc8013ea4u);
+		v1 += ((v0 << 4) + 0xad90777du) ^ (v0 + s0) ^ ((v0 >> 5) + 0x7e95761eu);
+	}
+	return v0;
+}
+
+// shaders/random.glsl:45-51
+__device__ __forceinline__ uint32_t pt_lcg(uint32_t &prev)
+{
+	prev = 1664525u * prev + 1013904223u;
+	return prev & 0x00FFFFFFu;
+}
+
+// shaders/random.glsl:54-57 (exact: 24-bit integer scaled by 2^-24)
+__device__ __forceinline__ float pt_rnd(uint32_t &prev)
+{
+	return (float)pt_lcg(prev) * (1.0f / 16777216.0f);
+}
+
+// sin/cos of 2*pi*u, u = k/2^24 in [0,1): exact quadrant reduction, then the Taylor
+// polynomials of sin(pi/2 x), cos(pi/2 x) on |x| <= 1/2 (Horner, fused).  This DEFINES the
+// implementation-defined GLSL sin/cos of random.glsl:59-64 for this build.
+__device__ __forceinline__ void pt_sincos_2pi(float u, float &s_out, float &c_out)
+{
+	const float S0 = 1.57079632679489662f, S1 = -0.645964097506246254f, S2 = 0.0796926262461670451f,
+	            S3 = -0.00468175413531868810f, S4 = 0.000160441184787359822f;
+	const float C1 = -1.23370055013616983f, C2 = 0.253669507901048014f, C3 = -0.0208634807633529609f,
+	            C4 = 0.000919260274839426580f;
+	float t = u * 4.0f;
+	int q = (int)(t + 0.5f);
+	float x = t - (float)q;
+	float x2 = x * x;
+	float sp = __builtin_fmaf(x2, S4, S3);
+	sp = __builtin_fmaf(x2, sp, S2);
+	sp = __builtin_fmaf(x2, sp, S1);
+	sp = __builtin_fmaf(x2, sp, S0);
+	float s = x * sp;
+	float cp = __builtin_fmaf(x2, C4, C3);
+	cp = __builtin_fmaf(x2, cp, C2);
+	cp = __builtin_fmaf(x2, cp, C1);
+	float c = __builtin_fmaf(x2, cp, 1.0f);
+	bool swap = q & 1;
+	float ss = swap ? c : s;
+	float cc = swap ? s : c;
+	// q&3: 0 -> (s, c); 1 -> (c, -s); 2 -> (-s, -c); 3 -> (-c, s)
+	s_out = (q & 2) ? -ss : ss;
+	c_out = (((q + 1) & 2) ? -cc : cc);
+}
+
+// shaders/random.glsl:59-64 (theta draw first, then z)
+__device__ __forceinline__ float3x pt_rnd_unit_vector(uint32_t &prev)
+{
+	float u = pt_rnd(prev);
+	float z = pt_rnd(prev) * 2.0f - 1.0f;
+	float r = __builtin_sqrtf(1.0f - z * z);
+	float s, c;
+	pt_sincos_2pi(u, s, c);
+	return { r * c, r * s, z };
+}
+
+// glm-style normalize: v * (1 / sqrt((x*x + y*y) + z*z))
+__device__ __forceinline__ float3x pt_normalize(float3x v)
+{
+	float inv = 1.0f / __builtin_sqrtf((v.x * v.x + v.y * v.y) + v.z * v.z);
+	return { v.x * inv, v.y * inv, v.z * inv };
+}
+
+// ---------------------------------------------------------------------- camera ray ----
+struct PtCamera
+{
+	float invView[16];
+	float invProj[16];
+};
+
+// raytrace.rgen:40-46 with inverse(view)/inverse(proj) hoisted to the host.  Matrix * vector in
+// glm's association: (m0*x + m1*y) + (m2*z + m3*w).
+__device__ __forceinline__ void pt_camera_ray(const PtCamera &cam, uint32_t W, uint32_t H, uint32_t px, uint32_t py,
+                                              float jx, float jy, float3x &o, float3x &d)
+{
+	float uvx = ((float)px + jx) / (float)W;
+	float uvy = ((float)py + jy) / (float)H;
+	float dx = uvx * 2.0f - 1.0f;
+	float dy = uvy * 2.0f - 1.0f;
+	const float *V = cam.invView, *P = cam.invProj;
+	o.x = (V[0] * 0.0f + V[4] * 0.0f) + (V[8] * 0.0f + V[12] * 1.0f);
+	o.y = (V[1] * 0.0f + V[5] * 0.0f) + (V[9] * 0.0f + V[13] * 1.0f);
+	o.z = (V[2] * 0.0f + V[6] * 0.0f) + (V[10] * 0.0f + V[14] * 1.0f);
+	float3x t;
+	t.x = (P[0] * dx + P[4] * dy) + (P[8] * 1.0f + P[12] * 1.0f);
+	t.y = (P[1] * dx + P[5] * dy) + (P[9] * 1.0f + P[13] * 1.0f);
+	t.z = (P[2] * dx + P[6] * dy) + (P[10] * 1.0f + P[14] * 1.0f);
+	float3x n = pt_normalize(t);
+	d.x = (V[0] * n.x + V[4] * n.y) + (V[8] * n.z + V[12] * 0.0f);
+	d.y = (V[1] * n.x + V[5] * n.y) + (V[9] * n.z + V[13] * 0.0f);
+	d.z = (V[2] * n.x + V[6] * n.y) + (V[10] * n.z + V[14] * 0.0f);
+}
+
+// ------------------------------------------------------- watertight ray/triangle test ----
+// Woop, Benthin, Wald, "Watertight Ray/Triangle Intersection" (JCGT 2013), without backface
+// culling (the instance sets TRIANGLE_FACING_CULL_DISABLE, VulkanRaytracing.cpp:405).
+struct PtRayShear
+{
+	int kx, ky, kz;
+	float Sx, Sy, Sz;
+};
+
+__device__ __forceinline__ float pt_sel3(float3x v, int k)
+{
+	return k == 0 ? v.x : (k == 1 ? v.y : v.z);
+}
+
+__device__ __forceinline__ PtRayShear pt_ray_shear(float3x d)
+{
+	PtRayShear rs;
+	int kz = 0;
+	float m = __builtin_fabsf(d.x);
+	if (__builtin_fabsf(d.y) > m)
+	{
+		kz = 1;
+		m = __builtin_fabsf(d.y);
+	}
+	if (__builtin_fabsf(d.z) > m) kz = 2;
+	int kx = kz + 1;
+	if (kx == 3) kx = 0;
+	int ky = kx + 1;
+	if (ky == 3) ky = 0;
+	float dz = pt_sel3(d, kz);
+	if (dz < 0.0f)
+	{
+		int t = kx;
+		kx = ky;
+		ky = t;
+	}
+	rs.kx = kx;
+	rs.ky = ky;
+	rs.kz = kz;
+	rs.Sx = pt_sel3(d, kx) / dz;
+	rs.Sy = pt_sel3(d, ky) / dz;
+	rs.Sz = 1.0f / dz;
+	return rs;
+}
+
+struct PtBest
+{
+	float t;        // closest accepted distance so far (initially tmax)
+	uint32_t prim;  // PT_NO_HIT until a candidate is accepted
+	float V, W, det;
+};
+
+// Candidate accepted iff tmin < t and (t < best.t, or t == best.t with a lower primitive id).
+__device__ __forceinline__ void pt_tri_test(float3x o, const PtRayShear &rs, float tmin, float3x p0, float3x p1,
+                                            float3x p2, uint32_t prim, PtBest &best)
+{
+	float3x A = { p0.x - o.x, p0.y - o.y, p0.z - o.z };
+	float3x B = { p1.x - o.x, p1.y - o.y, p1.z - o.z };
+	float3x C = { p2.x - o.x, p2.y - o.y, p2.z - o.z };
+	float Akz = pt_sel3(A, rs.kz), Bkz = pt_sel3(B, rs.kz), Ckz = pt_sel3(C, rs.kz);
+	float Ax = pt_sel3(A, rs.kx) - rs.Sx * Akz, Ay = pt_sel3(A, rs.ky) - rs.Sy * Akz;
+	float Bx = pt_sel3(B, rs.kx) - rs.Sx * Bkz, By = pt_sel3(B, rs.ky) - rs.Sy * Bkz;
+	float Cx = pt_sel3(C, rs.kx) - rs.Sx * Ckz, Cy = pt_sel3(C, rs.ky) - rs.Sy * Ckz;
+	float U = Cx * By - Cy * Bx;
+	float V = Ax * Cy - Ay * Cx;
+	float W = Bx * Ay - By * Ax;
+	if (U == 0.0f || V == 0.0f || W == 0.0f)
+	{
+		U = (float)((double)Cx * (double)By - (double)Cy * (double)Bx);
+		V = (float)((double)Ax * (double)Cy - (double)Ay * (double)Cx);
+		W = (float)((double)Bx * (double)Ay - (double)By * (double)Ax);
+	}
+	if ((U < 0.0f || V < 0.0f || W < 0.0f) && (U > 0.0f || V > 0.0f || W > 0.0f)) return;
+	float det = (U + V) + W;
+	if (det == 0.0f) return;
+	float Az = rs.Sz * Akz, Bz = rs.Sz * Bkz, Cz = rs.Sz * Ckz;
+	float T = (U * Az + V * Bz) + W * Cz;
+	float t = T / det;
+	if (t > tmin && (t < best.t || (t == best.t && best.prim != PT_NO_HIT && prim < best.prim)))
+	{
+		best.t = t;
+		best.prim = prim;
+		best.V = V;
+		best.W = W;
+		best.det = det;
+	}
+}
+
+__device__ __forceinline__ PtHit pt_finish_hit(const PtBest &b, float tmax)
+{
+	PtHit h;
+	h.prim = b.prim;
+	if (b.prim != PT_NO_HIT)
+	{
+		h.t = b.t;
+		h.u = b.V / b.det;
+		h.v = b.W / b.det;
+	}
+	else
+	{
+		h.t = tmax;
+		h.u = 0.0f;
+		h.v = 0.0f;
+	}
+	return h;
+}
+
+// ------------------------------------------------------------------ wide BVH layout ----
+// 64-byte quantised BVH4 node: one 64 B-aligned record = four 16-byte loads per lane.
+//   child box c, axis a:  lo = origin[a] + qlo[a][c] * 2^(exp[a]-127),  hi likewise with qhi.
+//   An empty child slot has qlo = 255, qhi = 0 on every axis (never intersected).
+//   child[c]: bit 31 = leaf.  inner: node index.  leaf: bits 30..28 = triangle count - 1,
+//   bits 27..0 = first triangle in the leaf-ordered triangle array.
+struct __attribute__((aligned(64))) PtNode4
+{
+	float origin[3];
+	uint32_t exps;       // exp_x | exp_y << 8 | exp_z << 16 (biased exponents of the power-of-two scales)
+	uint32_t child[4];
+	uint32_t qlo[3];     // qlo[a] = 4 bytes, one per child
+	uint32_t qhi[3];
+	uint32_t pad[2];
+};
+static_assert(sizeof(PtNode4) == 64, "PtNode4 must be 64 bytes");
+
+#define PT_LEAF_FLAG 0x80000000u
+#define PT_EMPTY_CHILD 0xFFFFFFFEu  // unused child slot (never reported as hit)
+#define PT_TRAVERSAL_DONE 0xFFFFFFFFu
+#define PT_LEAF_MAX 4
+
+// 48-byte leaf triangle: three 16-byte loads.  (v0.xyz, v1.x) (v1.yz, v2.xy) (v2.z, prim, -, -)
+struct __attribute__((aligned(16))) PtTri48
+{
+	float v0[3];
+	float v1[3];
+	float v2[3];
+	uint32_t prim;
+	uint32_t pad[2];
+};
+static_assert(sizeof(PtTri48) == 48, "PtTri48 must be 48 bytes");
+
+struct PtSceneDev
+{
+	const PtVertex *vertices;
+	const uint32_t *indices;
+	const PtMaterial *materials;
+	const uint32_t *matIndices;
+	const PtNode4 *nodes;
+	const PtTri48 *tris;
+	uint32_t nTris;
+	uint32_t nNodes;
+};

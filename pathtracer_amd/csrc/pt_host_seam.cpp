@@ -1,0 +1,669 @@
+// Host seam of the path tracer: scene load and camera, the code that sits in front of the
+// ray-tracing pipeline in the reference (main.cpp:1101-1190 loadModel, main.cpp:1465-1480
+// updateUniformBuffer).  Pure host C++, no GPU calls; exported through the C ABI of
+// include/pt_hip.h.
+//
+// The OBJ/MTL reader is written from scratch but follows the observable behaviour of the
+// tinyobjloader v1.0.6 header the reference vendors (external/tinyobjloader), because that
+// behaviour defines primitive order, vertex order and the exact float bits of the scene:
+//   * numbers: decimal digits accumulated in double, fraction digits weighted by a 1e-k table,
+//     optional exponent applied as ldexp(m * 5^e, e), result narrowed to float
+//     (tiny_obj_loader.h:474-597) -- deliberately NOT strtof;
+//   * faces: i, i/j, i//k, i/j/k with 1-based or negative (relative) indices (:425-429,
+//     :691-731), polygons triangulated as a fan (0,k-1,k) (:908-931);
+//   * `usemtl` switching flushes the pending faces into the SAME shape (:1528-1555); `g`/`o`
+//     start a new shape and drop a shape whose pending face list is empty (:1597-1660);
+//   * a missing .mtl is only a warning (:1347-1355, :1587-1593).
+// tests/test_host_seam.py pins all of this against the real library (tests/golden/ref_seam.npz).
+#include "../../include/pt_hip.h"
+
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <fstream>
+#include <map>
+#include <sstream>
+#include <string>
+#include <unordered_map>
+#include <vector>
+
+struct PtSceneData
+{
+	std::vector<PtVertex> vertices;
+	std::vector<uint32_t> indices;
+	std::vector<PtMaterial> materials;
+	std::vector<uint32_t> matIndices;
+	std::string warnings;
+};
+
+static thread_local std::string g_seamError;
+const char *pt_seam_last_error() { return g_seamError.c_str(); }
+
+namespace
+{
+struct Cursor
+{
+	const char *p;
+	const char *end;
+	bool done() const { return p >= end; }
+	void skipBlank()
+	{
+		while (p < end && (*p == ' ' || *p == '\t')) ++p;
+	}
+	// token = run of characters up to blank / CR
+	void token(const char *&b, const char *&e)
+	{
+		skipBlank();
+		b = p;
+		while (p < end && *p != ' ' && *p != '\t' && *p != '\r') ++p;
+		e = p;
+	}
+};
+
+inline bool isDigit(char c) { return c >= '0' && c <= '9'; }
+
+// Number grammar and arithmetic of tinyobjloader's parser (see file header).
+bool parseNumber(const char *s, const char *e, double &out)
+{
+	if (s >= e) return false;
+	bool neg = false;
+	if (*s == '+' || *s == '-')
+	{
+		neg = (*s == '-');
+		++s;
+	}
+	else if (!isDigit(*s))
+		return false;
+	double m = 0.0;
+	int nread = 0;
+	while (s != e && isDigit(*s))
+	{
+		m *= 10;
+		m += (int)(*s - '0');
+		++s;
+		++nread;
+	}
+	if (nread == 0) return false;
+	int exp10 = 0;
+	bool more = (s != e);
+	if (more)
+	{
+		if (*s == '.')
+		{
+			static const double frac[] = { 1.0, 0.1, 0.01, 0.001, 0.0001, 0.00001, 0.000001, 0.0000001 };
+			++s;
+			int k = 1;
+			while (s != e && isDigit(*s))
+			{
+				m += (int)(*s - '0') * (k < 8 ? frac[k] : std::pow(10.0, -k));
+				++k;
+				++s;
+			}
+		}
+		else if (*s != 'e' && *s != 'E')
+			more = false;
+	}
+	if (more && s != e && (*s == 'e' || *s == 'E'))
+	{
+		++s;
+		bool eneg = false;
+		if (s != e && (*s == '+' || *s == '-'))
+		{
+			eneg = (*s == '-');
+			++s;
+		}
+		else if (s == e || !isDigit(*s))
+			return false;
+		int n = 0;
+		while (s != e && isDigit(*s))
+		{
+			exp10 = exp10 * 10 + (int)(*s - '0');
+			++s;
+			++n;
+		}
+		if (eneg) exp10 = -exp10;
+		if (n == 0) return false;
+	}
+	double v = exp10 ? std::ldexp(m * std::pow(5.0, exp10), exp10) : m;
+	out = (neg ? -1 : 1) * v;
+	return true;
+}
+
+float readReal(Cursor &c, double dflt = 0.0)
+{
+	const char *b, *e;
+	c.token(b, e);
+	double v = dflt;
+	parseNumber(b, e, v);
+	return (float)v;
+}
+
+int resolveIndex(int idx, int n)
+{
+	if (idx > 0) return idx - 1;
+	if (idx == 0) return 0;
+	return n + idx;
+}
+
+struct Corner
+{
+	int v = -1, vt = -1, vn = -1;
+};
+
+void skipIndexField(Cursor &c)
+{
+	while (c.p < c.end && *c.p != '/' && *c.p != ' ' && *c.p != '\t' && *c.p != '\r') ++c.p;
+}
+
+Corner readCorner(Cursor &c, int nv, int nvn, int nvt)
+{
+	Corner k;
+	k.v = resolveIndex(atoi(c.p), nv);
+	skipIndexField(c);
+	if (c.done() || *c.p != '/') return k;
+	++c.p;
+	if (!c.done() && *c.p == '/')
+	{
+		++c.p;
+		k.vn = resolveIndex(atoi(c.p), nvn);
+		skipIndexField(c);
+		return k;
+	}
+	k.vt = resolveIndex(atoi(c.p), nvt);
+	skipIndexField(c);
+	if (c.done() || *c.p != '/') return k;
+	++c.p;
+	k.vn = resolveIndex(atoi(c.p), nvn);
+	skipIndexField(c);
+	return k;
+}
+
+// Splits text into lines on \n, \r\n or bare \r.
+std::vector<std::string> splitLines(const std::string &text)
+{
+	std::vector<std::string> lines;
+	std::string cur;
+	for (size_t i = 0; i < text.size(); ++i)
+	{
+		char ch = text[i];
+		if (ch == '\n')
+		{
+			lines.push_back(cur);
+			cur.clear();
+		}
+		else if (ch == '\r')
+		{
+			if (i + 1 < text.size() && text[i + 1] == '\n') ++i;
+			lines.push_back(cur);
+			cur.clear();
+		}
+		else
+			cur.push_back(ch);
+	}
+	if (!cur.empty()) lines.push_back(cur);
+	return lines;
+}
+
+bool readFile(const std::string &path, std::string &out)
+{
+	std::ifstream f(path.c_str(), std::ios::binary);
+	if (!f) return false;
+	std::stringstream ss;
+	ss << f.rdbuf();
+	out = ss.str();
+	return true;
+}
+
+std::string firstWord(const char *s)
+{
+	while (*s == ' ' || *s == '\t' || *s == '\n' || *s == '\v' || *s == '\f' || *s == '\r') ++s;
+	const char *b = s;
+	while (*s && *s != ' ' && *s != '\t' && *s != '\n' && *s != '\v' && *s != '\f' && *s != '\r') ++s;
+	return std::string(b, s);
+}
+
+bool isBlank(char c) { return c == ' ' || c == '\t'; }
+
+struct MtlEntry
+{
+	std::string name;
+	float kd[3] = { 0, 0, 0 };
+	float ke[3] = { 0, 0, 0 };
+};
+
+void parseMtl(const std::string &text, std::vector<MtlEntry> &mats, std::map<std::string, int> &byName)
+{
+	MtlEntry cur;
+	for (std::string line : splitLines(text))
+	{
+		size_t last = line.find_last_not_of(" \t");
+		line = (last == std::string::npos) ? std::string() : line.substr(0, last + 1);
+		if (line.empty()) continue;
+		const char *t = line.c_str();
+		while (isBlank(*t)) ++t;
+		if (*t == '\0' || *t == '#') continue;
+		if (strncmp(t, "newmtl", 6) == 0 && isBlank(t[6]))
+		{
+			if (!cur.name.empty())
+			{
+				byName.insert(std::make_pair(cur.name, (int)mats.size()));
+				mats.push_back(cur);
+			}
+			cur = MtlEntry();
+			cur.name = firstWord(t + 7);
+			continue;
+		}
+		if (t[0] == 'K' && (t[1] == 'd' || t[1] == 'e') && isBlank(t[2]))
+		{
+			Cursor c{ t + 2, t + strlen(t) };
+			float *dst = (t[1] == 'd') ? cur.kd : cur.ke;
+			dst[0] = readReal(c);
+			dst[1] = readReal(c);
+			dst[2] = readReal(c);
+			continue;
+		}
+	}
+	byName.insert(std::make_pair(cur.name, (int)mats.size()));
+	mats.push_back(cur);
+}
+
+struct Shape
+{
+	std::vector<Corner> corners;   // 3 per triangle
+	std::vector<int> materialIds;  // 1 per triangle
+};
+
+bool flushFaces(Shape &shape, const std::vector<std::vector<Corner>> &faces, int material)
+{
+	if (faces.empty()) return false;
+	for (const auto &face : faces)
+	{
+		for (size_t k = 2; k < face.size(); ++k)
+		{
+			shape.corners.push_back(face[0]);
+			shape.corners.push_back(face[k - 1]);
+			shape.corners.push_back(face[k]);
+			shape.materialIds.push_back(material);
+		}
+	}
+	return true;
+}
+
+// Vertex identity as the reference's unordered_map<Vertex,...> sees it: float ==, so that
+// -0.0f and +0.0f coincide (main.cpp:109-112).  Key = bit pattern with -0 folded to +0.
+struct VertexKey
+{
+	uint32_t w[11];
+	bool operator==(const VertexKey &o) const { return memcmp(w, o.w, sizeof(w)) == 0; }
+};
+struct VertexKeyHash
+{
+	size_t operator()(const VertexKey &k) const
+	{
+		uint64_t h = 1469598103934665603ull;
+		for (uint32_t x : k.w)
+		{
+			h ^= x;
+			h *= 1099511628211ull;
+		}
+		return (size_t)h;
+	}
+};
+VertexKey makeKey(const PtVertex &v)
+{
+	VertexKey k;
+	memcpy(k.w, &v, sizeof(k.w));
+	for (uint32_t &x : k.w)
+		if (x == 0x80000000u) x = 0;
+	return k;
+}
+}  // namespace
+
+extern "C" int pt_load_obj(const char *obj_path, PtSceneData **out)
+{
+	if (!obj_path || !out)
+	{
+		g_seamError = "pt_load_obj: null argument";
+		return PT_EINVAL;
+	}
+	std::string text;
+	if (!readFile(obj_path, text))
+	{
+		g_seamError = std::string("pt_load_obj: cannot open ") + obj_path;
+		return PT_EIO;
+	}
+	std::string path(obj_path), mtlDir;
+	size_t slash = path.find_last_of("/\\");
+	if (slash != std::string::npos) mtlDir = path.substr(0, slash);
+	mtlDir += "/";
+
+	std::vector<float> v, vn, vt;
+	std::vector<Shape> shapes;
+	std::vector<MtlEntry> mtl;
+	std::map<std::string, int> mtlByName;
+	std::vector<std::vector<Corner>> pending;
+	Shape shape;
+	int material = -1;
+	std::string warnings;
+
+	for (const std::string &line : splitLines(text))
+	{
+		if (line.empty()) continue;
+		const char *t = line.c_str();
+		const char *lineEnd = t + line.size();
+		while (isBlank(*t)) ++t;
+		if (*t == '\0' || *t == '#') continue;
+		if (t[0] == 'v' && isBlank(t[1]))
+		{
+			Cursor c{ t + 2, lineEnd };
+			for (int k = 0; k < 3; ++k) v.push_back(readReal(c));
+			continue;
+		}
+		if (t[0] == 'v' && t[1] == 'n' && isBlank(t[2]))
+		{
+			Cursor c{ t + 3, lineEnd };
+			for (int k = 0; k < 3; ++k) vn.push_back(readReal(c));
+			continue;
+		}
+		if (t[0] == 'v' && t[1] == 't' && isBlank(t[2]))
+		{
+			Cursor c{ t + 3, lineEnd };
+			for (int k = 0; k < 2; ++k) vt.push_back(readReal(c));
+			continue;
+		}
+		if (t[0] == 'f' && isBlank(t[1]))
+		{
+			Cursor c{ t + 2, lineEnd };
+			c.skipBlank();
+			std::vector<Corner> face;
+			while (!c.done() && *c.p != '\r' && *c.p != '\n')
+			{
+				face.push_back(readCorner(c, (int)(v.size() / 3), (int)(vn.size() / 3), (int)(vt.size() / 2)));
+				while (!c.done() && (*c.p == ' ' || *c.p == '\t' || *c.p == '\r')) ++c.p;
+			}
+			pending.push_back(face);
+			continue;
+		}
+		if (strncmp(t, "usemtl", 6) == 0 && isBlank(t[6]))
+		{
+			std::string name = firstWord(t + 7);
+			auto it = mtlByName.find(name);
+			int id = (it == mtlByName.end()) ? -1 : it->second;
+			if (id != material)
+			{
+				flushFaces(shape, pending, material);
+				pending.clear();
+				material = id;
+			}
+			continue;
+		}
+		if (strncmp(t, "mtllib", 6) == 0 && isBlank(t[6]))
+		{
+			std::string rest(t + 7);
+			bool found = false;
+			size_t pos = 0;
+			while (pos <= rest.size())
+			{
+				size_t sp = rest.find(' ', pos);
+				std::string fn = rest.substr(pos, sp == std::string::npos ? std::string::npos : sp - pos);
+				pos = (sp == std::string::npos) ? rest.size() + 1 : sp + 1;
+				std::string mtlText;
+				if (readFile(mtlDir + fn, mtlText))
+				{
+					parseMtl(mtlText, mtl, mtlByName);
+					found = true;
+					break;
+				}
+				warnings += "WARN: Material file [ " + mtlDir + fn + " ] not found.\n";
+			}
+			if (!found) warnings += "WARN: Failed to load material file(s). Use default material.\n";
+			continue;
+		}
+		if ((t[0] == 'g' || t[0] == 'o') && isBlank(t[1]))
+		{
+			if (flushFaces(shape, pending, material)) shapes.push_back(shape);
+			shape = Shape();
+			pending.clear();
+			continue;
+		}
+	}
+	if (flushFaces(shape, pending, material) || !shape.corners.empty()) shapes.push_back(shape);
+
+	// ---- PathTracer::loadModel (main.cpp:1122-1189) ----
+	PtSceneData *sd = new PtSceneData();
+	sd->warnings = warnings;
+	for (const MtlEntry &m : mtl)
+	{
+		PtMaterial pm;
+		for (int k = 0; k < 3; ++k)
+		{
+			pm.diffuse[k] = m.kd[k];
+			pm.emission[k] = m.ke[k];
+		}
+		sd->materials.push_back(pm);
+	}
+	const uint32_t matCount = (uint32_t)sd->materials.size();
+	PtMaterial grey = { { 0.5f, 0.5f, 0.5f }, { 0.0f, 0.0f, 0.0f } };
+	sd->materials.push_back(grey);
+
+	std::unordered_map<VertexKey, uint32_t, VertexKeyHash> unique;
+	for (const Shape &s : shapes)
+	{
+		for (int id : s.materialIds) sd->matIndices.push_back(id == -1 ? matCount : (uint32_t)id);
+		for (size_t tri = 0; tri + 2 < s.corners.size(); tri += 3)
+		{
+			float flat[3] = { 0, 0, 1 };
+			bool haveFlat = false;
+			for (int j = 0; j < 3; ++j)
+			{
+				const Corner &c = s.corners[tri + j];
+				if (c.v < 0 || (size_t)(3 * c.v + 2) >= v.size())
+				{
+					g_seamError = "pt_load_obj: face references a vertex that does not exist";
+					delete sd;
+					return PT_EIO;
+				}
+				PtVertex vert;
+				for (int k = 0; k < 3; ++k) vert.pos[k] = v[3 * c.v + k];
+				if (c.vn >= 0 && (size_t)(3 * c.vn + 2) < vn.size())
+				{
+					for (int k = 0; k < 3; ++k) vert.normal[k] = vn[3 * c.vn + k];
+				}
+				else
+				{
+					// Extension (reference: out-of-bounds read, main.cpp:1162-1164): flat normal.
+					if (!haveFlat)
+					{
+						const float *p0 = &v[3 * s.corners[tri].v], *p1 = &v[3 * s.corners[tri + 1].v],
+						            *p2 = &v[3 * s.corners[tri + 2].v];
+						float e1[3] = { p1[0] - p0[0], p1[1] - p0[1], p1[2] - p0[2] };
+						float e2[3] = { p2[0] - p0[0], p2[1] - p0[1], p2[2] - p0[2] };
+						float cx = e1[1] * e2[2] - e2[1] * e1[2];
+						float cy = e1[2] * e2[0] - e2[2] * e1[0];
+						float cz = e1[0] * e2[1] - e2[0] * e1[1];
+						float l2 = (cx * cx + cy * cy) + cz * cz;
+						if (l2 > 0.0f)
+						{
+							float inv = 1.0f / std::sqrt(l2);
+							flat[0] = cx * inv;
+							flat[1] = cy * inv;
+							flat[2] = cz * inv;
+						}
+						haveFlat = true;
+					}
+					for (int k = 0; k < 3; ++k) vert.normal[k] = flat[k];
+				}
+				if (c.vt >= 0 && (size_t)(2 * c.vt + 1) < vt.size())
+				{
+					vert.texCoord[0] = vt[2 * c.vt];
+					vert.texCoord[1] = 1.0f - vt[2 * c.vt + 1];
+				}
+				else
+				{
+					vert.texCoord[0] = 0.0f;
+					vert.texCoord[1] = 0.0f;
+				}
+				vert.color[0] = vert.color[1] = vert.color[2] = 1.0f;
+				VertexKey key = makeKey(vert);
+				auto it = unique.find(key);
+				uint32_t id;
+				if (it == unique.end())
+				{
+					id = (uint32_t)sd->vertices.size();
+					unique.emplace(key, id);
+					sd->vertices.push_back(vert);
+				}
+				else
+					id = it->second;
+				sd->indices.push_back(id);
+			}
+		}
+	}
+	*out = sd;
+	return PT_OK;
+}
+
+extern "C" void pt_scene_free(PtSceneData *s) { delete s; }
+extern "C" uint32_t pt_scene_n_vertices(const PtSceneData *s) { return (uint32_t)s->vertices.size(); }
+extern "C" uint32_t pt_scene_n_indices(const PtSceneData *s) { return (uint32_t)s->indices.size(); }
+extern "C" uint32_t pt_scene_n_materials(const PtSceneData *s) { return (uint32_t)s->materials.size(); }
+extern "C" const PtVertex *pt_scene_vertices(const PtSceneData *s) { return s->vertices.data(); }
+extern "C" const uint32_t *pt_scene_indices(const PtSceneData *s) { return s->indices.data(); }
+extern "C" const PtMaterial *pt_scene_materials(const PtSceneData *s) { return s->materials.data(); }
+extern "C" const uint32_t *pt_scene_mat_indices(const PtSceneData *s) { return s->matIndices.data(); }
+extern "C" const char *pt_scene_warnings(const PtSceneData *s) { return s->warnings.c_str(); }
+
+// ---------------------------------------------------------------------------- camera ----
+// Column-major float[16] (element (column c, row r) at [4c + r]), the memory layout of glm::mat4
+// that the reference memcpy's into its uniform buffer (main.cpp:1479).  Arithmetic follows glm
+// 1.0.1 operation by operation so the matrices are bit-identical to the reference's:
+// lookAtRH (glm/ext/matrix_transform.inl:153-173), perspectiveRH_NO
+// (glm/ext/matrix_clip_space.inl:249-262 -- see SURVEY.md section 0 for why NO and not ZO),
+// compute_inverse<4,4> (glm/detail/func_matrix.inl:347-404).
+namespace
+{
+struct V3
+{
+	float x, y, z;
+};
+inline float dotv(V3 a, V3 b) { return (a.x * b.x + a.y * b.y) + a.z * b.z; }
+inline V3 crossv(V3 a, V3 b) { return { a.y * b.z - b.y * a.z, a.z * b.x - b.z * a.x, a.x * b.y - b.x * a.y }; }
+inline V3 unitv(V3 a)
+{
+	float inv = 1.0f / std::sqrt(dotv(a, a));
+	return { a.x * inv, a.y * inv, a.z * inv };
+}
+}  // namespace
+
+extern "C" void pt_look_at(const float eye[3], const float center[3], const float up[3], float m[16])
+{
+	V3 e = { eye[0], eye[1], eye[2] };
+	V3 fwd = unitv({ center[0] - eye[0], center[1] - eye[1], center[2] - eye[2] });
+	V3 side = unitv(crossv(fwd, { up[0], up[1], up[2] }));
+	V3 upv = crossv(side, fwd);
+	const float cols[16] = { side.x, upv.x, -fwd.x, 0.0f, side.y, upv.y, -fwd.y, 0.0f,
+		                     side.z, upv.z, -fwd.z, 0.0f, -dotv(side, e), -dotv(upv, e), dotv(fwd, e), 1.0f };
+	memcpy(m, cols, sizeof(cols));
+}
+
+extern "C" void pt_perspective(float fovy, float aspect, float zNear, float zFar, float m[16])
+{
+	const float th = std::tan(fovy / 2.0f);
+	memset(m, 0, 16 * sizeof(float));
+	m[0] = 1.0f / (aspect * th);
+	m[5] = 1.0f / (th);
+	m[10] = -(zFar + zNear) / (zFar - zNear);
+	m[11] = -1.0f;
+	m[14] = -(2.0f * zFar * zNear) / (zFar - zNear);
+}
+
+extern "C" void pt_inverse4(const float a[16], float out[16])
+{
+	auto M = [&](int c, int r) { return a[4 * c + r]; };
+	// 2x2 sub-determinants, named s<rows><cols> after the rows/columns of the minor they span
+	const float c00 = M(2, 2) * M(3, 3) - M(3, 2) * M(2, 3);
+	const float c02 = M(1, 2) * M(3, 3) - M(3, 2) * M(1, 3);
+	const float c03 = M(1, 2) * M(2, 3) - M(2, 2) * M(1, 3);
+	const float c04 = M(2, 1) * M(3, 3) - M(3, 1) * M(2, 3);
+	const float c06 = M(1, 1) * M(3, 3) - M(3, 1) * M(1, 3);
+	const float c07 = M(1, 1) * M(2, 3) - M(2, 1) * M(1, 3);
+	const float c08 = M(2, 1) * M(3, 2) - M(3, 1) * M(2, 2);
+	const float c10 = M(1, 1) * M(3, 2) - M(3, 1) * M(1, 2);
+	const float c11 = M(1, 1) * M(2, 2) - M(2, 1) * M(1, 2);
+	const float c12 = M(2, 0) * M(3, 3) - M(3, 0) * M(2, 3);
+	const float c14 = M(1, 0) * M(3, 3) - M(3, 0) * M(1, 3);
+	const float c15 = M(1, 0) * M(2, 3) - M(2, 0) * M(1, 3);
+	const float c16 = M(2, 0) * M(3, 2) - M(3, 0) * M(2, 2);
+	const float c18 = M(1, 0) * M(3, 2) - M(3, 0) * M(1, 2);
+	const float c19 = M(1, 0) * M(2, 2) - M(2, 0) * M(1, 2);
+	const float c20 = M(2, 0) * M(3, 1) - M(3, 0) * M(2, 1);
+	const float c22 = M(1, 0) * M(3, 1) - M(3, 0) * M(1, 1);
+	const float c23 = M(1, 0) * M(2, 1) - M(2, 0) * M(1, 1);
+	const float f0[4] = { c00, c00, c02, c03 }, f1[4] = { c04, c04, c06, c07 }, f2[4] = { c08, c08, c10, c11 };
+	const float f3[4] = { c12, c12, c14, c15 }, f4[4] = { c16, c16, c18, c19 }, f5[4] = { c20, c20, c22, c23 };
+	const float v0[4] = { M(1, 0), M(0, 0), M(0, 0), M(0, 0) }, v1[4] = { M(1, 1), M(0, 1), M(0, 1), M(0, 1) };
+	const float v2[4] = { M(1, 2), M(0, 2), M(0, 2), M(0, 2) }, v3[4] = { M(1, 3), M(0, 3), M(0, 3), M(0, 3) };
+	float adj[16];
+	for (int r = 0; r < 4; ++r)
+	{
+		const float sa = (r & 1) ? -1.0f : 1.0f, sb = -sa;
+		adj[0 + r] = ((v1[r] * f0[r] - v2[r] * f1[r]) + v3[r] * f2[r]) * sa;
+		adj[4 + r] = ((v0[r] * f0[r] - v2[r] * f3[r]) + v3[r] * f4[r]) * sb;
+		adj[8 + r] = ((v0[r] * f1[r] - v1[r] * f3[r]) + v3[r] * f5[r]) * sa;
+		adj[12 + r] = ((v0[r] * f2[r] - v1[r] * f4[r]) + v2[r] * f5[r]) * sb;
+	}
+	const float det = (M(0, 0) * adj[0] + M(0, 1) * adj[4]) + (M(0, 2) * adj[8] + M(0, 3) * adj[12]);
+	const float rdet = 1.0f / det;
+	for (int i = 0; i < 16; ++i) out[i] = adj[i] * rdet;
+}
+
+extern "C" void pt_reference_camera(uint32_t width, uint32_t height, float view[16], float proj[16])
+{
+	const float eye[3] = { 0.0f, 1.0f, 3.5f }, center[3] = { 0.0f, 1.0f, 0.0f }, up[3] = { 0.0f, 1.0f, 0.0f };
+	pt_look_at(eye, center, up, view);
+	const float fovy = 45.0f * 0.01745329251994329576923690768489f;  // glm::radians(45.0f)
+	pt_perspective(fovy, width / static_cast<float>(height), 0.1f, 10.0f, proj);
+	proj[5] *= -1;  // "Flip y axis" (main.cpp:1477)
+}
+
+// ---------------------------------------------------------------------- image writers ----
+extern "C" int pt_write_pfm(const char *path, const float *rgba, uint32_t w, uint32_t h)
+{
+	FILE *f = fopen(path, "wb");
+	if (!f)
+	{
+		g_seamError = std::string("pt_write_pfm: cannot open ") + path;
+		return PT_EIO;
+	}
+	fprintf(f, "PF\n%u %u\n-1.0\n", w, h);
+	std::vector<float> row(3 * (size_t)w);
+	for (uint32_t y = 0; y < h; ++y)
+	{
+		const float *src = rgba + 4 * (size_t)(h - 1 - y) * w;  // PFM stores bottom row first
+		for (uint32_t x = 0; x < w; ++x)
+			for (int k = 0; k < 3; ++k) row[3 * x + k] = src[4 * x + k];
+		fwrite(row.data(), sizeof(float), row.size(), f);
+	}
+	fclose(f);
+	return PT_OK;
+}
+
+extern "C" int pt_write_ppm(const char *path, const uint8_t *rgba8, uint32_t w, uint32_t h)
+{
+	FILE *f = fopen(path, "wb");
+	if (!f)
+	{
+		g_seamError = std::string("pt_write_ppm: cannot open ") + path;
+		return PT_EIO;
+	}
+	fprintf(f, "P6\n%u %u\n255\n", w, h);
+	std::vector<uint8_t> row(3 * (size_t)w);
+	for (uint32_t y = 0; y < h; ++y)
+	{
+		for (uint32_t x = 0; x < w; ++x)
+			for (int k = 0; k < 3; ++k) row[3 * x + k] = rgba8[4 * ((size_t)y * w + x) + k];
+		fwrite(row.data(), 1, row.size(), f);
+	}
+	fclose(f);
+	return PT_OK;
+}

@@ -1,0 +1,47 @@
+// Host-callable launchers of the wavefront path-tracing kernels (pt_trace.hip).
+#pragma once
+#include "pt_device_common.h"
+
+#define PT_MAX_DEPTH 64     // upper bound for max_depth (reference: 20)
+#define PT_SPILL_STACK 72   // traversal stack entries per lane beyond the LDS-resident ones
+
+// Per-frame device counters, zeroed by k_frame_begin.  count[d] = rays queued for bounce d.
+struct PtFrameCounters
+{
+	uint32_t count[PT_MAX_DEPTH + 1];
+	uint32_t headExtend[PT_MAX_DEPTH + 1];
+	uint32_t headShade[PT_MAX_DEPTH + 1];
+};
+
+// Path/ray queues in HBM (SoA float4 streams, capacity = W*H*spp_per_frame records each).
+struct PtQueues
+{
+	float4 *rayO[2];  // (origin.xyz, rng state)          ping-pong across bounces
+	float4 *rayD[2];  // (direction.xyz, path id)
+	float4 *thr[2];   // (throughput.xyz, -)
+	float4 *hits;     // PtHit per queued ray
+	float4 *rad;      // radiance per path id (sample-major: id = sample*W*H + pixel)
+};
+
+struct PtLaunchCfg
+{
+	uint32_t persistentBlocks;  // grid of the persistent extend/shade kernels
+	uint32_t *spill;            // persistentBlocks*256*PT_SPILL_STACK words
+	uint32_t spillStride;       // persistentBlocks*256
+};
+
+void ptLaunchFrameBegin(PtFrameCounters *fc, uint32_t nPaths, hipStream_t s);
+void ptLaunchFrameEnd(const PtFrameCounters *fc, int depth, unsigned long long *stats, hipStream_t s);
+void ptLaunchGenerate(const PtCamera &cam, uint32_t W, uint32_t H, uint32_t spp, uint32_t seedWord, int centreJitter,
+                      const PtQueues &q, hipStream_t s);
+void ptLaunchExtend(const PtSceneDev &sc, bool brute, const uint32_t *count, uint32_t *head, const float4 *rayO,
+                    const float4 *rayD, float4 *hits, float tmin, float tmax, const PtLaunchCfg &cfg, hipStream_t s);
+void ptLaunchShade(const PtSceneDev &sc, const uint8_t *primEmissive, const uint32_t *count, uint32_t *head,
+                   const PtQueues &q, int in, uint32_t *countOut, int lastBounce, const PtLaunchCfg &cfg, hipStream_t s);
+void ptLaunchAccumulate(const PtQueues &q, uint32_t WH, uint32_t spp, float4 *image, uint32_t lframe, int mode,
+                        hipStream_t s);
+void ptLaunchDebugRng(uint32_t n, const uint32_t *v0, const uint32_t *v1, uint32_t nSteps, uint32_t *outTea,
+                      uint32_t *outLcg, float *outUnit, hipStream_t s);
+void ptLaunchPackRays(const float *rays, uint32_t n, float4 *rayO, float4 *rayD, hipStream_t s);
+void ptLaunchSetU32(uint32_t *p, uint32_t v, hipStream_t s);
+void ptLaunchSrgb8(const float4 *image, uint32_t n, void *out, hipStream_t s);
