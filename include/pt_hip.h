@@ -72,6 +72,10 @@ typedef struct PtStats
 	uint32_t bvh_tris;
 	uint32_t reserved;
 	double build_ms;            /* last pt_build_accel, device time */
+	/* Traversal work counters, only collected under PT_PROFILE_TRAVERSAL (instrumented kernel): */
+	uint64_t trav_nodes;        /* wide nodes fetched */
+	uint64_t trav_tris;         /* ray/triangle tests */
+	uint64_t trav_hits;         /* rays that found a hit */
 } PtStats;
 
 typedef struct pt_ctx pt_ctx;
@@ -160,7 +164,8 @@ int pt_write_image_from_device(pt_ctx *ctx, const void *dev_rgba32f);
  * sRGB RGBA, W*H*4 bytes.  Synchronises. */
 int pt_read_image_srgb8(pt_ctx *ctx, uint8_t *rgba8);
 
-#define PT_PROFILE_KERNELS 1  /* bracket traversal/shade launches with HIP events */
+#define PT_PROFILE_KERNELS 1    /* bracket traversal/shade launches with HIP events */
+#define PT_PROFILE_TRAVERSAL 2  /* run the instrumented traversal kernel (counts node fetches / triangle tests) */
 int pt_set_profiling(pt_ctx *ctx, int flags);
 int pt_get_stats(pt_ctx *ctx, PtStats *out);
 int pt_reset_stats(pt_ctx *ctx);

@@ -17,6 +17,7 @@ PT_ACCEL_BRUTE_FORCE = 1
 PT_ACCUM_MEAN = 0
 PT_ACCUM_SUM = 1
 PT_PROFILE_KERNELS = 1
+PT_PROFILE_TRAVERSAL = 2
 
 
 class PtStats(C.Structure):
@@ -24,7 +25,8 @@ class PtStats(C.Structure):
                 ("frames_rendered", C.c_uint64), ("extend_ms_total", C.c_double), ("extend_launches", C.c_uint64),
                 ("shade_ms_total", C.c_double), ("shade_launches", C.c_uint64), ("bvh_nodes", C.c_uint32),
                 ("bvh_depth", C.c_uint32), ("bvh_tris", C.c_uint32), ("reserved", C.c_uint32),
-                ("build_ms", C.c_double)]
+                ("build_ms", C.c_double), ("trav_nodes", C.c_uint64), ("trav_tris", C.c_uint64),
+                ("trav_hits", C.c_uint64)]
 
 
 # every symbol include/pt_hip.h declares: name -> (restype, argtypes)

@@ -58,7 +58,7 @@ struct pt_ctx
 	size_t queueCap = 0;  // records
 	float4 *image = nullptr;
 	PtFrameCounters *counters = nullptr;
-	unsigned long long *dStats = nullptr;  // [0] rays_total [1] rays_last_frame
+	unsigned long long *dStats = nullptr;  // [0] rays_total [1] rays_last_frame [2..4] traversal counters
 	PtLaunchCfg cfg = {};
 
 	int profiling = 0;
@@ -210,7 +210,7 @@ int traceQueue0(pt_ctx *c, uint32_t n, float tmin, float tmax)
 {
 	ptLaunchFrameBegin(c->counters, n, c->stream);
 	ptLaunchExtend(sceneDev(c), c->brute, &c->counters->count[0], &c->counters->headExtend[0], c->q.rayO[0],
-	               c->q.rayD[0], c->q.hits, tmin, tmax, c->cfg, c->stream);
+	               c->q.rayD[0], c->q.hits, tmin, tmax, c->cfg, nullptr, c->stream);
 	PT_HIP(c, hipGetLastError());
 	return PT_OK;
 }
@@ -249,8 +249,8 @@ extern "C" pt_ctx *pt_create(int device)
 	bool ok = hipStreamCreateWithFlags(&c->ownStream, hipStreamNonBlocking) == hipSuccess;
 	c->stream = c->ownStream;
 	ok = ok && hipMalloc(&c->counters, sizeof(PtFrameCounters)) == hipSuccess;
-	ok = ok && hipMalloc(&c->dStats, 2 * sizeof(unsigned long long)) == hipSuccess;
-	ok = ok && hipMemset(c->dStats, 0, 2 * sizeof(unsigned long long)) == hipSuccess;
+	ok = ok && hipMalloc(&c->dStats, 5 * sizeof(unsigned long long)) == hipSuccess;
+	ok = ok && hipMemset(c->dStats, 0, 5 * sizeof(unsigned long long)) == hipSuccess;
 	c->cfg.persistentBlocks = (uint32_t)c->numCUs * 4u;
 	c->cfg.spillStride = c->cfg.persistentBlocks * 256u;
 	ok = ok && hipMalloc(&c->cfg.spill, sizeof(uint32_t) * (size_t)c->cfg.spillStride * PT_SPILL_STACK) == hipSuccess;
@@ -462,7 +462,7 @@ extern "C" int pt_render_frame(pt_ctx *c)
 			hipEventRecord(e0, s);
 		}
 		ptLaunchExtend(sc, c->brute, &c->counters->count[d], &c->counters->headExtend[d], c->q.rayO[in], c->q.rayD[in],
-		               c->q.hits, c->tmin, c->tmax, c->cfg, s);
+		               c->q.hits, c->tmin, c->tmax, c->cfg, (c->profiling & PT_PROFILE_TRAVERSAL) ? c->dStats + 2 : nullptr, s);
 		if (e1) hipEventRecord(e1, s);
 		ptLaunchShade(sc, c->dPrimEmissive, &c->counters->count[d], &c->counters->headShade[d], c->q, in,
 		              &c->counters->count[d + 1], d == c->maxDepth - 1, c->cfg, s);
@@ -553,7 +553,7 @@ extern "C" int pt_get_stats(pt_ctx *c, PtStats *out)
 {
 	if (!c || !out) return fail(c, PT_EINVAL, "pt_get_stats: null argument");
 	PT_HIP(c, hipSetDevice(c->device));
-	unsigned long long h[2] = { 0, 0 };
+	unsigned long long h[5] = { 0, 0, 0, 0, 0 };
 	PT_HIP(c, hipMemcpyAsync(h, c->dStats, sizeof(h), hipMemcpyDeviceToHost, c->stream));
 	PT_HIP(c, hipStreamSynchronize(c->stream));
 	drainEvents(c);
@@ -570,6 +570,9 @@ extern "C" int pt_get_stats(pt_ctx *c, PtStats *out)
 	out->bvh_depth = c->accel.depth;
 	out->bvh_tris = c->accel.nTris;
 	out->build_ms = c->buildMs;
+	out->trav_nodes = h[2];
+	out->trav_tris = h[3];
+	out->trav_hits = h[4];
 	return PT_OK;
 }
 
@@ -578,7 +581,7 @@ extern "C" int pt_reset_stats(pt_ctx *c)
 	if (!c) return fail(nullptr, PT_EINVAL, "null context");
 	PT_HIP(c, hipStreamSynchronize(c->stream));
 	drainEvents(c);
-	PT_HIP(c, hipMemset(c->dStats, 0, 2 * sizeof(unsigned long long)));
+	PT_HIP(c, hipMemset(c->dStats, 0, 5 * sizeof(unsigned long long)));
 	c->extendMs = c->shadeMs = 0.0;
 	c->extendLaunches = c->shadeLaunches = c->framesRendered = 0;
 	return PT_OK;

@@ -35,7 +35,8 @@ void ptLaunchFrameEnd(const PtFrameCounters *fc, int depth, unsigned long long *
 void ptLaunchGenerate(const PtCamera &cam, uint32_t W, uint32_t H, uint32_t spp, uint32_t seedWord, int centreJitter,
                       const PtQueues &q, hipStream_t s);
 void ptLaunchExtend(const PtSceneDev &sc, bool brute, const uint32_t *count, uint32_t *head, const float4 *rayO,
-                    const float4 *rayD, float4 *hits, float tmin, float tmax, const PtLaunchCfg &cfg, hipStream_t s);
+                    const float4 *rayD, float4 *hits, float tmin, float tmax, const PtLaunchCfg &cfg,
+                    unsigned long long *travStats /* null = uninstrumented kernel */, hipStream_t s);
 void ptLaunchShade(const PtSceneDev &sc, const uint8_t *primEmissive, const uint32_t *count, uint32_t *head,
                    const PtQueues &q, int in, uint32_t *countOut, int lastBounce, const PtLaunchCfg &cfg, hipStream_t s);
 void ptLaunchAccumulate(const PtQueues &q, uint32_t WH, uint32_t spp, float4 *image, uint32_t lframe, int mode,

@@ -45,8 +45,9 @@ struct Stack
 // Closest hit against the wide BVH.  Culling is conservative (quantised boxes padded at build time,
 // far plane padded here), every surviving triangle runs the exact pt_tri_test, and acceptance is
 // order independent (t, then primitive id), so the result equals the brute-force definition.
+template <bool kStats>
 __device__ __forceinline__ PtHit traverseBvh4(const PtSceneDev &sc, float3x o, float3x d, float tmin, float tmax,
-                                              Stack &st)
+                                              Stack &st, uint32_t &nodeFetches, uint32_t &triTests)
 {
 	PtRayShear rs = pt_ray_shear(d);
 	PtBest best = { tmax, PT_NO_HIT, 0.0f, 0.0f, 1.0f };
@@ -61,6 +62,7 @@ __device__ __forceinline__ PtHit traverseBvh4(const PtSceneDev &sc, float3x o, f
 	{
 		if (!(cur & PT_LEAF_FLAG))
 		{
+			if (kStats) ++nodeFetches;
 			const uint4 *np = reinterpret_cast<const uint4 *>(sc.nodes + cur);
 			uint4 n0 = np[0], n1 = np[1], n2 = np[2], n3 = np[3];
 			float sx = __uint_as_float((n0.w & 0xFFu) << 23), sy = __uint_as_float(((n0.w >> 8) & 0xFFu) << 23),
@@ -113,6 +115,7 @@ __device__ __forceinline__ PtHit traverseBvh4(const PtSceneDev &sc, float3x o, f
 		{
 			uint32_t first = cur & 0x0FFFFFFFu;
 			uint32_t cnt = ((cur >> 28) & 7u) + 1u;
+			if (kStats) triTests += cnt;
 			for (uint32_t i = 0; i < cnt; ++i)
 			{
 				const float4 *tp = reinterpret_cast<const float4 *>(sc.tris + first + i);
@@ -169,11 +172,12 @@ __global__ void __launch_bounds__(kBlock)
 }
 
 // -------------------------------------------------------------------------- extend ----
-template <bool kBrute>
+template <bool kBrute, bool kStats>
 __global__ void __launch_bounds__(kBlock)
     k_extend(PtSceneDev sc, const uint32_t *count, uint32_t *head, const float4 *rayO, const float4 *rayD,
-             float4 *hits, float tmin, float tmax, uint32_t *spill, uint32_t spillStride)
+             float4 *hits, float tmin, float tmax, uint32_t *spill, uint32_t spillStride, unsigned long long *trav)
 {
+	uint32_t nodeFetches = 0, triTests = 0, nHits = 0;
 	__shared__ uint32_t ldsStack[kBrute ? 1 : kLdsStack][kBlock];
 	const uint32_t n = *count;
 	const int lane = threadIdx.x & 63;
@@ -194,9 +198,32 @@ __global__ void __launch_bounds__(kBlock)
 			float4 ro = rayO[i], rd = rayD[i];
 			float3x o = { ro.x, ro.y, ro.z }, d = { rd.x, rd.y, rd.z };
 			PtHit h;
-			if (kBrute) h = traverseBrute(sc, o, d, tmin, tmax);
-			else h = traverseBvh4(sc, o, d, tmin, tmax, st);
+			if (kBrute)
+			{
+				h = traverseBrute(sc, o, d, tmin, tmax);
+				if (kStats) triTests += sc.nTris;
+			}
+			else h = traverseBvh4<kStats>(sc, o, d, tmin, tmax, st, nodeFetches, triTests);
+			if (kStats && h.prim != PT_NO_HIT) ++nHits;
 			hits[i] = make_float4(h.t, h.u, h.v, __uint_as_float(h.prim));
+		}
+	}
+	if (kStats)
+	{
+		// per-wave sums, three atomics per wave at kernel end
+		unsigned long long a = nodeFetches, b = triTests, c = nHits;
+#pragma unroll
+		for (int o = 32; o > 0; o >>= 1)
+		{
+			a += __shfl_xor(a, o);
+			b += __shfl_xor(b, o);
+			c += __shfl_xor(c, o);
+		}
+		if (lane == 0)
+		{
+			atomicAdd(&trav[0], a);
+			atomicAdd(&trav[1], b);
+			atomicAdd(&trav[2], c);
 		}
 	}
 }
@@ -424,14 +451,23 @@ void ptLaunchGenerate(const PtCamera &cam, uint32_t W, uint32_t H, uint32_t spp,
 }
 
 void ptLaunchExtend(const PtSceneDev &sc, bool brute, const uint32_t *count, uint32_t *head, const float4 *rayO,
-                    const float4 *rayD, float4 *hits, float tmin, float tmax, const PtLaunchCfg &cfg, hipStream_t s)
+                    const float4 *rayD, float4 *hits, float tmin, float tmax, const PtLaunchCfg &cfg,
+                    unsigned long long *travStats, hipStream_t s)
 {
+#define PT_EXT(B, S)                                                                                                 \
+	k_extend<B, S><<<cfg.persistentBlocks, kBlock, 0, s>>>(sc, count, head, rayO, rayD, hits, tmin, tmax, cfg.spill, \
+	                                                       cfg.spillStride, travStats)
 	if (brute)
-		k_extend<true><<<cfg.persistentBlocks, kBlock, 0, s>>>(sc, count, head, rayO, rayD, hits, tmin, tmax, cfg.spill,
-		                                                      cfg.spillStride);
+	{
+		if (travStats) PT_EXT(true, true);
+		else PT_EXT(true, false);
+	}
 	else
-		k_extend<false><<<cfg.persistentBlocks, kBlock, 0, s>>>(sc, count, head, rayO, rayD, hits, tmin, tmax, cfg.spill,
-		                                                       cfg.spillStride);
+	{
+		if (travStats) PT_EXT(false, true);
+		else PT_EXT(false, false);
+	}
+#undef PT_EXT
 }
 
 void ptLaunchShade(const PtSceneDev &sc, const uint8_t *primEmissive, const uint32_t *count, uint32_t *head,
