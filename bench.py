@@ -74,6 +74,7 @@ def main():
 
     import pathtracer_amd as pa
     from pathtracer_amd.api import PT_ACCUM_MEAN, PT_ACCUM_SUM, PT_PROFILE_KERNELS, PT_PROFILE_TRAVERSAL
+    from pathtracer_amd import multigpu
 
     W, H, S, D = a.width, a.height, a.spp_per_frame, a.depth
     scene = pa.scenes.cornell_box()
@@ -84,7 +85,8 @@ def main():
     rt.resize(W, H)
     rt.setCamera(view, proj)
     rt.setParams(spp_per_frame=S, max_depth=D, tmin=1e-3, tmax=1e4, seed=0, max_frames=0)
-    rt.setFrameSchedule(first=rank, stride=world)
+    first, stride = multigpu.frame_schedule(rank, world)
+    rt.setFrameSchedule(first=first, stride=stride)
     rt.setAccumMode(PT_ACCUM_SUM if world > 1 else PT_ACCUM_MEAN)
 
     def barrier():
@@ -101,7 +103,7 @@ def main():
         rt.raytrace(frames)
         rt.synchronize()
         if dist is not None:
-            dist.reduce(img_t, dst=0, op=dist.ReduceOp.SUM)
+            multigpu.reduce_sum_image(img_t, dist, dst=0)
             torch.cuda.synchronize()
 
     # ---- untimed: traversal statistics for the roofline (node visits / triangle tests per ray) ----
@@ -146,7 +148,7 @@ def main():
     if a.out_image and rank == 0:
         img = rt.readImage()
         if world > 1:
-            img[..., :3] /= float(world * a.steps)
+            multigpu.finalize_mean(img, world * a.steps)
         np.save(a.out_image, img)
 
     if rank == 0:

@@ -82,6 +82,8 @@ def _bind(L):
     L.pto_render_frame.restype = C.c_uint64
     L.pto_render_frame.argtypes = [C.POINTER(Scene), vp, vp, vp, u32, u32, C.POINTER(Params), u32, u32, C.c_int, vp,
                                    C.c_int]
+    L.pto_render_pixels.restype = C.c_uint64
+    L.pto_render_pixels.argtypes = [C.POINTER(Scene), vp, vp, vp, u32, u32, C.POINTER(Params), u32, vp, u32, vp]
     L.pto_primary_hits.argtypes = [C.POINTER(Scene), vp, vp, vp, u32, u32, f32, f32, vp]
     L.pto_trace_rays.argtypes = [C.POINTER(Scene), vp, vp, u32, f32, f32, vp]
     L.pto_morton_codes.argtypes = [C.POINTER(Scene), vp, vp, vp]
@@ -206,6 +208,18 @@ class OracleScene:
                                            first_frame + k * frame_stride, lframe0 + k, int(accum_sum), _p(image),
                                            nthreads)
         return image, int(rays)
+
+    def render_pixels(self, view, proj, W, H, pixels, gframe=0, spp_per_frame=10, max_depth=20, tmin=1e-3, tmax=1e4,
+                      seed=0):
+        """Per-dispatch colour of the listed pixels (linear index y*W+x) for global frame `gframe`."""
+        px = np.ascontiguousarray(pixels, dtype=np.uint32)
+        out = np.zeros((px.size, 3), dtype=np.float32)
+        v = np.ascontiguousarray(view, dtype=np.float32)
+        p = np.ascontiguousarray(proj, dtype=np.float32)
+        pp = Params(spp_per_frame, max_depth, tmin, tmax, seed)
+        lib().pto_render_pixels(C.byref(self.c), self.bvh, _p(v), _p(p), W, H, C.byref(pp), gframe, _p(px), px.size,
+                                _p(out))
+        return out
 
     def morton(self):
         n = self.n_tris

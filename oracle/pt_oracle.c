@@ -648,6 +648,22 @@ uint64_t pto_render_frame(const PtoScene *sc, const PtoBvh *bvh, const float vie
 	return rays;
 }
 
+/* The per-dispatch colour (accumHitValue / MAX_SAMPLES, raytrace.rgen:85) of selected pixels only:
+ * lets a test compare a full-size GPU frame against the oracle on a pixel sample. out: n*3. */
+uint64_t pto_render_pixels(const PtoScene *sc, const PtoBvh *bvh, const float view[16], const float proj[16],
+                           uint32_t W, uint32_t H, const PtoParams *pp, uint32_t gframe, const uint32_t *pixels,
+                           uint32_t n, float *out)
+{
+	float invView[16], invProj[16];
+	pto_inverse4(view, invView);
+	pto_inverse4(proj, invProj);
+	uint64_t rays = 0;
+#pragma omp parallel for schedule(dynamic, 16) reduction(+ : rays)
+	for (int64_t i = 0; i < (int64_t)n; ++i)
+		render_pixel(sc, bvh, invView, invProj, W, H, pixels[i] % W, pixels[i] / W, pp, gframe, out + 3 * i, &rays);
+	return rays;
+}
+
 /* Primary-ray closest hits at frame 0 (jitter = pixel centre): hits[W*H]. */
 void pto_primary_hits(const PtoScene *sc, const PtoBvh *bvh, const float view[16], const float proj[16], uint32_t W,
                       uint32_t H, float tmin, float tmax, PtoHit *hits)

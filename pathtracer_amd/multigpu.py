@@ -1,0 +1,36 @@
+"""Multi-GPU sample-stream split.  The reference is single-device; this is
+the build's own sharding rule, kept in one place so bench.py and the gloo CPU tests agree:
+
+* rank r of G renders the GLOBAL frames r, r+G, r+2G, ... (disjoint tea() seed words, and only
+  global frame 0 uses the pixel-centre jitter of raytrace.rgen:38);
+* every rank accumulates raw per-frame sums (PT_ACCUM_SUM) against a replicated scene/BVH;
+* one reduce(sum) of the W*H*4 fp32 image to rank 0 (RCCL over xGMI on GPUs, gloo in the CPU
+  tests), then rank 0 divides by the total number of frames.  No collective on the data path.
+"""
+from __future__ import annotations
+
+
+def frame_schedule(rank: int, world: int):
+    """(first, stride) for pt_set_frame_schedule."""
+    if not (0 <= rank < world):
+        raise ValueError(f"rank {rank} outside world of {world}")
+    return rank, world
+
+
+def global_frames(rank: int, world: int, frames_per_rank: int):
+    first, stride = frame_schedule(rank, world)
+    return [first + k * stride for k in range(frames_per_rank)]
+
+
+def reduce_sum_image(image_tensor, dist, dst: int = 0):
+    """In-place reduce(sum) of the per-rank sum images onto `dst` (torch.distributed module passed in
+    so the same code runs over nccl(=RCCL) and gloo)."""
+    dist.reduce(image_tensor, dst=dst, op=dist.ReduceOp.SUM)
+    return image_tensor
+
+
+def finalize_mean(image, total_frames: int):
+    """Rank 0: sums -> mean over all frames of all ranks; alpha back to 1 (raytrace.rgen:92)."""
+    image[..., :3] /= float(total_frames)
+    image[..., 3] = 1.0
+    return image

@@ -1,0 +1,123 @@
+"""GPU: the device-built acceleration structure -- structural validity of the quantised BVH4 and
+hit-for-hit agreement of its traversal with the brute-force definition on incoherent rays."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+LEAF = 0x80000000
+EMPTY = 0xFFFFFFFE
+
+
+def random_rays(n, lo, hi, seed):
+    rng = np.random.default_rng(seed)
+    o = rng.uniform(lo, hi, size=(n, 3)).astype(np.float32)
+    d = rng.normal(size=(n, 3)).astype(np.float32)
+    d /= np.linalg.norm(d, axis=1, keepdims=True)
+    d[: n // 50, 0] = 0.0  # axis-parallel / zero components
+    d[n // 50: n // 25, 1] = 0.0
+    d[n // 25: 3 * n // 50, 2] = -0.0
+    return np.concatenate([o, d], axis=1).astype(np.float32)
+
+
+def validate_bvh(nodes, tris, scene):
+    """Every primitive in exactly one leaf; every child box (dequantised as the traversal does)
+    contains its triangles / its sub-tree's boxes; all nodes reachable once."""
+    n_tris = scene.n_tris
+    assert sorted(tris["prim"].tolist()) == list(range(n_tris))
+    pos = scene.vertices[scene.indices.reshape(-1, 3), :3]
+    assert np.array_equal(tris["v0"], pos[tris["prim"], 0]) and np.array_equal(tris["v2"], pos[tris["prim"], 2])
+    if n_tris == 0:
+        return 0
+    seen_nodes = np.zeros(len(nodes), dtype=np.int32)
+    seen_tris = np.zeros(len(tris), dtype=np.int32)
+    depth_max = 0
+    stack = [(0, None, None, 1)]
+    while stack:
+        ni, plo, phi, depth = stack.pop()
+        depth_max = max(depth_max, depth)
+        seen_nodes[ni] += 1
+        nd = nodes[ni]
+        scale = np.array([np.uint32(((int(nd["exps"]) >> (8 * a)) & 0xFF) << 23) for a in range(3)],
+                         dtype=np.uint32).view(np.float32).astype(np.float64)
+        org = nd["origin"].astype(np.float64)
+        for c in range(4):
+            ref = int(nd["child"][c])
+            if ref == EMPTY:
+                assert np.all(nd["qlo"][:, c] == 255) and np.all(nd["qhi"][:, c] == 0)
+                continue
+            lo = org + nd["qlo"][:, c].astype(np.float64) * scale
+            hi = org + nd["qhi"][:, c].astype(np.float64) * scale
+            if plo is not None:  # nested inside the parent's box for this node (up to quantisation rounding)
+                eps = 1e-6 * (1.0 + np.abs(phi).max())
+                assert np.all(lo >= plo - eps) and np.all(hi <= phi + eps)
+            if ref & LEAF:
+                first, cnt = ref & 0x0FFFFFFF, ((ref >> 28) & 7) + 1
+                assert 1 <= cnt <= 4 and first + cnt <= len(tris)
+                seen_tris[first:first + cnt] += 1
+                p = np.stack([tris["v0"][first:first + cnt], tris["v1"][first:first + cnt],
+                              tris["v2"][first:first + cnt]], axis=1).astype(np.float64)
+                assert np.all(p >= lo) and np.all(p <= hi), "triangle sticks out of its quantised leaf box"
+            else:
+                assert 0 < ref < len(nodes)
+                stack.append((ref, lo, hi, depth + 1))
+    assert np.all(seen_nodes == 1) and np.all(seen_tris == 1)
+    return depth_max
+
+
+@pytest.mark.parametrize("scene_name", ["cornell", "grid", "random", "single", "two", "five"])
+def test_bvh_structure(rt, pa, scene_name):
+    sc = {"cornell": pa.scenes.cornell_box, "grid": lambda: pa.scenes.grid_mesh(40, 33),
+          "random": lambda: pa.scenes.random_triangles(20000, extent=50.0, edge=1.0),
+          "single": lambda: pa.scenes.random_triangles(0), "two": lambda: pa.scenes.random_triangles(0),
+          "five": lambda: pa.scenes.random_triangles(3)}[scene_name]()
+    if scene_name == "single":  # one triangle only
+        sc = pa.Scene(sc.vertices, sc.indices[:3], sc.materials, sc.mat_indices[:1])
+    rt.buildBlas(sc)
+    nodes, tris = rt.debugReadBvh()
+    depth = validate_bvh(nodes, tris, sc)
+    st = rt.stats()
+    assert st.bvh_nodes == len(nodes) and st.bvh_tris == sc.n_tris and st.bvh_depth == depth
+
+
+@pytest.mark.parametrize("scene_name,n_rays", [("cornell", 400000), ("grid", 300000), ("random", 300000)])
+def test_bvh_traversal_equals_brute_force_definition(rt, pa, O, scene_name, n_rays):
+    """Incoherent rays (secondary-bounce-like), zero direction components included: GPU BVH4
+    traversal == oracle (which is itself checked against brute force) == GPU brute force, bit for bit
+    (t, u, v, primitive id)."""
+    from pathtracer_amd.api import PT_ACCEL_BRUTE_FORCE
+    if scene_name == "cornell":
+        sc, lo, hi = pa.scenes.cornell_box(), (-1.0, 0.01, -1.0), (1.0, 1.98, 3.0)
+    elif scene_name == "grid":
+        sc, lo, hi = pa.scenes.grid_mesh(90, 70), (-1.2, -0.3, -1.2), (1.2, 1.6, 1.2)
+    else:
+        sc, lo, hi = pa.scenes.random_triangles(60000, extent=30.0, edge=1.5), (0.0, 0.0, 0.0), (30.0, 30.0, 30.0)
+    rays = random_rays(n_rays, lo, hi, seed=42)
+    osc = O.OracleScene(sc.vertices, sc.indices, sc.materials, sc.mat_indices)
+    want = osc.trace(rays)
+    rt.buildBlas(sc)
+    got = rt.debugTrace(rays)
+    assert np.array_equal(got["prim"], want["prim"]), int((got["prim"] != want["prim"]).sum())
+    assert np.array_equal(got.view(np.uint32), want.view(np.uint32))
+    assert 0.05 < (got["prim"] != 0xFFFFFFFF).mean()
+    if sc.n_tris <= 20000:
+        rt.buildBlas(sc, PT_ACCEL_BRUTE_FORCE)
+        sub = rays[:50000]
+        assert np.array_equal(rt.debugTrace(sub).view(np.uint32), want[:50000].view(np.uint32))
+        assert np.array_equal(osc.trace(sub[:5000], brute=True).view(np.uint32), want[:5000].view(np.uint32))
+
+
+def test_ties_resolve_to_lowest_primitive_id(rt, pa, O):
+    """Two coincident triangles and a shared edge: equal t -> lowest primitive id wins (the build's
+    documented tie-break; the Vulkan spec leaves it open)."""
+    v = np.zeros((6, 11), dtype=np.float32)
+    v[:, 0:3] = [[-1, -1, 0], [1, -1, 0], [0, 1, 0], [-1, -1, 0], [1, -1, 0], [0, 1, 0]]
+    v[:, 5] = 1.0
+    sc = pa.Scene(v, np.array([3, 4, 5, 0, 1, 2], dtype=np.uint32), np.array([[.5, .5, .5, 0, 0, 0]], dtype=np.float32),
+                  np.zeros(2, dtype=np.uint32))
+    rays = np.array([[0, 0, 2, 0, 0, -1], [0.2, -0.3, 1, 0, 0, -1], [0, 0, -3, 0, 0, 1]], dtype=np.float32)
+    rt.buildBlas(sc)
+    got = rt.debugTrace(rays)
+    assert list(got["prim"]) == [0, 0, 0]
+    osc = O.OracleScene(sc.vertices, sc.indices, sc.materials, sc.mat_indices)
+    assert np.array_equal(got.view(np.uint32), osc.trace(rays, brute=True).view(np.uint32))

@@ -1,0 +1,125 @@
+"""GPU: edge cases and error behaviour of the C ABI (empty and ragged inputs, limits, call order)."""
+import numpy as np
+import pytest
+
+from conftest import bits
+
+pytestmark = pytest.mark.gpu
+
+
+def test_empty_scene_renders_black(rt, pa):
+    sc = pa.Scene(np.zeros((0, 11), np.float32), np.zeros(0, np.uint32), np.array([[.5, .5, .5, 0, 0, 0]], np.float32),
+                  np.zeros(0, np.uint32))
+    rt.buildBlas(sc)
+    W, H = 33, 17
+    view, proj = pa.reference_camera(W, H)
+    rt.resize(W, H)
+    rt.setCamera(view, proj)
+    rt.setParams(spp_per_frame=3, max_depth=4)
+    rt.raytrace(2)
+    img = rt.readImage()
+    assert np.all(img[..., :3] == 0.0) and np.all(img[..., 3] == 1.0)
+    assert rt.stats().rays_total == 2 * W * H * 3  # every primary ray is traced once and misses
+    assert np.all(rt.debugPrimaryHits()["prim"] == 0xFFFFFFFF)
+
+
+@pytest.mark.parametrize("W,H,spp,depth", [(1, 1, 1, 1), (7, 5, 3, 2), (257, 3, 2, 8), (63, 65, 5, 20), (130, 2, 17, 3)])
+def test_ragged_extents_bit_exact(rt, pa, cornell, ocornell, W, H, spp, depth):
+    view, proj = pa.reference_camera(W, H)
+    rt.buildBlas(cornell)
+    rt.resize(W, H)
+    rt.setCamera(view, proj)
+    rt.setParams(spp_per_frame=spp, max_depth=depth, seed=9)
+    rt.raytrace(3)
+    want, rays = ocornell.render(view, proj, W, H, frames=3, spp_per_frame=spp, max_depth=depth, seed=9)
+    assert rt.stats().rays_total == rays
+    assert np.array_equal(bits(rt.readImage()), bits(want))
+
+
+def test_max_frames_stops_accumulation(rt, pa, cornell):
+    """VulkanRaytracing::raytrace is a no-op once frame >= maxRTFrames, but the counter keeps running
+    (VulkanRaytracing.cpp:877-886, 904-908)."""
+    W, H = 32, 32
+    view, proj = pa.reference_camera(W, H)
+    rt.buildBlas(cornell)
+    rt.resize(W, H)
+    rt.setCamera(view, proj)
+    rt.setParams(spp_per_frame=2, max_depth=4, max_frames=3)
+    rt.raytrace(3)
+    a = rt.readImage()
+    rays = rt.stats().rays_total
+    rt.raytrace(4)
+    assert rt.frame == 6
+    assert np.array_equal(bits(rt.readImage()), bits(a)) and rt.stats().rays_total == rays
+
+
+def test_resize_and_reupload_reset_state(rt, pa, cornell, ocornell):
+    view, proj = pa.reference_camera(48, 48)
+    rt.buildBlas(cornell)
+    rt.resize(48, 48)
+    rt.setCamera(view, proj)
+    rt.setParams(spp_per_frame=2, max_depth=4)
+    rt.raytrace(2)
+    rt.resize(20, 10)  # resize -> resetFrame (main.cpp:433-435)
+    assert rt.frame == -1
+    view, proj = pa.reference_camera(20, 10)
+    rt.setCamera(view, proj)
+    rt.raytrace(1)
+    want, _ = ocornell.render(view, proj, 20, 10, frames=1, spp_per_frame=2, max_depth=4)
+    assert np.array_equal(bits(rt.readImage()), bits(want))
+    # growing the queues (more spp) after the fact
+    rt.setParams(spp_per_frame=9, max_depth=4)
+    rt.resetFrame()
+    rt.raytrace(1)
+    want, _ = ocornell.render(view, proj, 20, 10, frames=1, spp_per_frame=9, max_depth=4)
+    assert np.array_equal(bits(rt.readImage()), bits(want))
+
+
+def test_degenerate_triangles_and_nan_are_harmless(rt, pa, O):
+    sc = pa.scenes.grid_mesh(6, 6)
+    v = sc.vertices.copy()
+    idx = np.concatenate([sc.indices, np.array([0, 0, 0, 1, 2, 1, 3, 3, 4], dtype=np.uint32)])  # zero-area triangles
+    mid = np.concatenate([sc.mat_indices, np.zeros(3, dtype=np.uint32)])
+    sc2 = pa.Scene(v, idx, sc.materials, mid)
+    rt.buildBlas(sc2)
+    rng = np.random.default_rng(3)
+    rays = np.concatenate([rng.uniform(-1, 1, (20000, 3)), rng.normal(size=(20000, 3))], axis=1).astype(np.float32)
+    rays[:, 1] = np.abs(rays[:, 1]) + 0.2
+    rays[0, 3:] = 0.0          # zero direction
+    rays[1, 3] = np.nan        # NaN direction
+    osc = O.OracleScene(sc2.vertices, sc2.indices, sc2.materials, sc2.mat_indices, use_bvh=False)
+    got, want = rt.debugTrace(rays), osc.trace(rays, brute=True)
+    assert np.array_equal(got["prim"], want["prim"])
+    assert got["prim"][0] == 0xFFFFFFFF and got["prim"][1] == 0xFFFFFFFF
+    assert not np.isin(got["prim"], [sc.n_tris, sc.n_tris + 1, sc.n_tris + 2]).any()
+
+
+def test_error_codes(rt, pa, cornell):
+    with pytest.raises(pa.PathTracerError) as e:
+        rt.raytrace(1)  # nothing uploaded
+    assert e.value.code == -1
+    bad = pa.Scene(cornell.vertices, cornell.indices.copy(), cornell.materials, cornell.mat_indices)
+    bad.indices[5] = 1000
+    with pytest.raises(pa.PathTracerError):
+        rt.uploadScene(bad)
+    bad2 = pa.Scene(cornell.vertices, cornell.indices, cornell.materials, cornell.mat_indices.copy())
+    bad2.mat_indices[0] = 99
+    with pytest.raises(pa.PathTracerError):
+        rt.uploadScene(bad2)
+    rt.uploadScene(cornell)
+    with pytest.raises(pa.PathTracerError):
+        rt.raytrace(1)  # accel not built
+    rt.buildBlas()
+    with pytest.raises(pa.PathTracerError):
+        rt.raytrace(1)  # no image / camera
+    with pytest.raises(pa.PathTracerError):
+        rt.resize(0, 10)
+    with pytest.raises(pa.PathTracerError) as e:
+        rt.setParams(max_depth=65)
+    assert e.value.code == -5
+    with pytest.raises(pa.PathTracerError):
+        rt.setParams(spp_per_frame=0)
+    with pytest.raises(pa.PathTracerError):
+        rt.setParams(tmin=-1.0)
+    with pytest.raises(pa.PathTracerError):
+        pa.HipRaytracing(4096)

@@ -1,0 +1,155 @@
+"""CPU: host seam (scene load + camera) -- oracle AND product -- against the reference's own
+tinyobjloader / glm (tests/golden/ref_seam.npz, produced by oracle/_ref from the headers under
+/root/reference/external, see oracle/ref_seam_dump.cpp + oracle/make_golden.py)."""
+import os
+import textwrap
+
+import numpy as np
+import pytest
+
+from conftest import GOLDEN, REFERENCE_MODELS, bits
+
+REF = np.load(os.path.join(GOLDEN, "ref_seam.npz"))
+HAVE_MODELS = os.path.isdir(REFERENCE_MODELS)
+
+
+def _mats(which, fn_look, fn_persp, fn_inv, row):
+    v = fn_look(row[0:3], row[3:6], row[6:9])
+    p = fn_persp(*[np.float32(x) for x in row[9:13]])
+    p = np.array(p, dtype=np.float32)
+    p[5] *= np.float32(-1)
+    return v, p, fn_inv(v), fn_inv(p)
+
+
+@pytest.mark.parametrize("impl", ["oracle", "product"])
+def test_camera_matrices_match_glm(impl, O, pa):
+    look, persp, inv, refcam = ((O.lookat, O.perspective, O.inverse4, O.reference_camera) if impl == "oracle" else
+                                (pa.look_at, pa.perspective, pa.inverse4, pa.reference_camera))
+    for row in REF["cameras"]:  # main.cpp:1465-1480 at several extents
+        W, H = int(row[0]), int(row[1])
+        v, p = refcam(W, H)
+        want = row[2:].reshape(4, 16)
+        for got, w in zip((v, p, inv(v), inv(p)), want):
+            assert np.array_equal(bits(got), bits(w)), (impl, W, H)
+    for row in REF["camkat"]:  # generic poses
+        got = _mats(impl, look, persp, inv, row)
+        for g, w in zip(got, row[13:].reshape(4, 16)):
+            assert np.array_equal(bits(g), bits(w)), impl
+
+
+def test_reference_camera_facts(pa):
+    """view = translation by (0,-1,-3.5); proj diag with aspect 1."""
+    v, p = pa.reference_camera(512, 512)
+    assert list(v[12:15]) == [0.0, -1.0, -3.5]
+    assert p[0] == np.float32(2.41421342) and p[5] == np.float32(-2.41421342)
+    assert p[10] == np.float32(-1.02020204) and p[11] == -1.0 and p[14] == np.float32(-0.202020213)
+
+
+def _tinyobj_arrays(obj):
+    idx = np.array([(a, c, b) for s in obj["shapes"] for (a, b, c) in s["indices"]], dtype=np.int32).reshape(-1, 3)
+    mid = np.array([x for s in obj["shapes"] for x in s["material_ids"]], dtype=np.int32)
+    mats = np.array([list(x["diffuse"]) + list(x["emission"]) for x in obj["materials"]], dtype=np.float32).reshape(-1, 6)
+    return idx, mid, mats
+
+
+@pytest.mark.skipif(not HAVE_MODELS, reason="/root/reference/models only exists in the build container")
+@pytest.mark.parametrize("model", ["cornell", "plane", "teapot", "viking_room"])
+def test_obj_oracle_matches_tinyobjloader(model):
+    import obj_oracle as oo
+    obj = oo.parse_obj(os.path.join(REFERENCE_MODELS, model + ".obj"))
+    assert np.array_equal(bits(obj["vertices"]), bits(REF[model + "_v"]))
+    assert np.array_equal(bits(obj["normals"]), bits(REF[model + "_vn"]))
+    assert np.array_equal(bits(obj["texcoords"]), bits(REF[model + "_vt"]))
+    idx, mid, mats = _tinyobj_arrays(obj)
+    assert np.array_equal(idx, REF[model + "_idx"])
+    assert np.array_equal(mid, REF[model + "_mid"])
+    assert np.array_equal(bits(mats), bits(REF[model + "_mat"]))
+    assert len(obj["shapes"]) == REF[model + "_shapes"].shape[0]
+
+
+@pytest.mark.skipif(not HAVE_MODELS, reason="/root/reference/models only exists in the build container")
+@pytest.mark.parametrize("model", ["cornell", "plane", "teapot", "viking_room"])
+def test_product_loader_matches_oracle_on_reference_models(model, pa):
+    import obj_oracle as oo
+    path = os.path.join(REFERENCE_MODELS, model + ".obj")
+    got, want = pa.load_obj(path), oo.load_model(path)
+    for k in ("vertices", "indices", "materials", "mat_indices"):
+        assert np.array_equal(getattr(got, k).view(np.uint32), want[k].view(np.uint32)), (model, k)
+
+
+def test_generated_cornell_equals_reference_tinyobj_output(pa, tmp_path):
+    """The Cornell box emitted by pathtracer_amd.scenes parses to exactly what the reference's
+    tinyobjloader makes of the reference's models/cornell.obj (fixture), signs of zero included."""
+    import obj_oracle as oo
+    path = pa.scenes.write_cornell_box(str(tmp_path))
+    obj = oo.parse_obj(path)
+    assert np.array_equal(bits(obj["vertices"]), bits(REF["cornell_v"]))
+    assert np.array_equal(bits(obj["normals"]), bits(REF["cornell_vn"]))
+    idx, mid, mats = _tinyobj_arrays(obj)
+    assert np.array_equal(idx, REF["cornell_idx"]) and np.array_equal(mid, REF["cornell_mid"])
+    assert np.array_equal(bits(mats), bits(REF["cornell_mat"]))
+    # loadModel facts quoted in SURVEY.md section 4 / 8(c)
+    sc = pa.load_obj(path)
+    want = oo.load_model(path)
+    for k in ("vertices", "indices", "materials", "mat_indices"):
+        assert np.array_equal(getattr(sc, k).view(np.uint32), want[k].view(np.uint32)), k
+    assert sc.vertices.shape == (64, 11) and sc.indices.size == 96 and sc.materials.shape == (5, 6)
+    assert list(sc.indices[:12]) == [0, 1, 2, 0, 2, 3, 4, 5, 6, 4, 6, 7]
+    assert list(sc.mat_indices) == [2, 2] + [3] * 26 + [0, 0, 1, 1]
+    assert list(sc.materials[4]) == [0.5, 0.5, 0.5, 0.0, 0.0, 0.0]
+    assert list(sc.materials[1]) == [0.0, 0.0, 0.0, 15.0, 15.0, 15.0]
+
+
+EDGE_OBJ = textwrap.dedent("""\
+    # edge cases: CRLF-free text; relative indices, pentagon fan, exponents, missing normals/uvs
+    mtllib edge.mtl other.mtl
+    v 0 0 0
+    v 1.5e0 0 0
+    v 1 1 -2.5E-1
+    v 0 1 +.5
+    v -0.000000 2 0.125
+    vt 0.25 0.75
+    vt 1 0
+    vn 0 0 1
+    usemtl glow
+    f 1/1/1 2/2/1 3/1/1 4/2/1 5/1/1
+    usemtl nosuch
+    f -5 -4 -3
+    g second
+    usemtl matte
+    f 1//1 3//1 4//1
+    f 2/2 3/1 5/2
+    """)
+EDGE_MTL = "newmtl matte\nKd 0.1 0.2 0.3\nnewmtl glow\nKd 0 0 0\nKe 2 3.5 1e1\n"
+
+
+@pytest.mark.parametrize("newline", ["\n", "\r\n"])
+def test_loader_edge_cases_product_equals_oracle(pa, tmp_path, newline):
+    import obj_oracle as oo
+    p = tmp_path / "edge.obj"
+    p.write_bytes(EDGE_OBJ.replace("\n", newline).encode())
+    (tmp_path / "edge.mtl").write_bytes(EDGE_MTL.replace("\n", newline).encode())
+    got, want = pa.load_obj(str(p)), oo.load_model(str(p))
+    for k in ("vertices", "indices", "materials", "mat_indices"):
+        assert np.array_equal(getattr(got, k).view(np.uint32), want[k].view(np.uint32)), k
+    # pentagon -> 3 triangles (fan), unknown material -> grey fallback index (= #materials in the .mtl)
+    assert got.indices.size == 3 * (3 + 1 + 2)
+    assert list(got.mat_indices) == [1, 1, 1, 2, 0, 0]
+    assert got.vertices[0, 9] == 0.25 and got.vertices[0, 10] == 0.25  # V flipped: 1 - 0.75
+
+
+def test_loader_missing_file_and_missing_mtl(pa, tmp_path):
+    with pytest.raises(pa.PathTracerError):
+        pa.load_obj(str(tmp_path / "does_not_exist.obj"))
+    p = tmp_path / "nomtl.obj"
+    p.write_text("mtllib missing.mtl\nv 0 0 0\nv 1 0 0\nv 0 1 0\nvn 0 0 1\nf 1//1 2//1 3//1\n")
+    sc = pa.load_obj(str(p))
+    assert "not found" in sc.warnings
+    assert sc.materials.shape == (1, 6) and list(sc.mat_indices) == [0]  # grey fallback only
+
+
+def test_loader_empty_obj(pa, tmp_path):
+    p = tmp_path / "empty.obj"
+    p.write_text("# nothing\n")
+    sc = pa.load_obj(str(p))
+    assert sc.indices.size == 0 and sc.vertices.shape[0] == 0 and sc.materials.shape == (1, 6)

@@ -1,0 +1,68 @@
+"""CPU: the N>1 path's sharding + reduce, world_size 2 over gloo.  The per-rank renderer is the
+oracle standing in for the GPU library (same frame schedule / sum-accumulation contract); what is
+under test is pathtracer_amd.multigpu -- the schedule, the reduce(sum) and the final mean -- i.e.
+the code bench.py runs over RCCL."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from conftest import ROOT
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, frames_per_rank, out_path):
+    import sys
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), OMP_NUM_THREADS="2")
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import oracle as O
+    import pathtracer_amd as pa
+    from pathtracer_amd import multigpu
+    sc = pa.scenes.cornell_box()
+    osc = O.OracleScene(sc.vertices, sc.indices, sc.materials, sc.mat_indices)
+    W, H = 32, 24
+    view, proj = O.reference_camera(W, H)
+    first, stride = multigpu.frame_schedule(rank, world)
+    img, _ = osc.render(view, proj, W, H, frames=frames_per_rank, spp_per_frame=4, max_depth=6, seed=11,
+                        first_frame=first, frame_stride=stride, accum_sum=True, nthreads=2)
+    t = torch.from_numpy(img)
+    multigpu.reduce_sum_image(t, dist, dst=0)
+    if rank == 0:
+        np.save(out_path, multigpu.finalize_mean(t.numpy(), world * frames_per_rank))
+    dist.destroy_process_group()
+
+
+def test_frame_schedule_partitions_frames():
+    from pathtracer_amd import multigpu
+    for world in (1, 2, 4, 8):
+        seen = sorted(f for r in range(world) for f in multigpu.global_frames(r, world, 5))
+        assert seen == list(range(5 * world))
+    with pytest.raises(ValueError):
+        multigpu.frame_schedule(2, 2)
+
+
+def test_two_rank_reduce_equals_single_process_render(tmp_path, O, ocornell):
+    world, fpr = 2, 3
+    out = str(tmp_path / "img.npy")
+    mp.spawn(_worker, args=(world, _free_port(), fpr, out), nprocs=world, join=True)
+    got = np.load(out)
+    W, H = 32, 24
+    view, proj = O.reference_camera(W, H)
+    ref, _ = ocornell.render(view, proj, W, H, frames=world * fpr, spp_per_frame=4, max_depth=6, seed=11, accum_sum=True)
+    ref[..., :3] /= float(world * fpr)
+    # same frames, different fp32 summation order: (f0+f2+f4)+(f1+f3+f5) vs f0+...+f5
+    assert np.allclose(got, ref, rtol=2e-6, atol=1e-6)
+    assert np.all(got[..., 3] == 1.0)
