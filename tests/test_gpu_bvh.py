@@ -48,9 +48,10 @@ def validate_bvh(nodes, tris, scene):
                 continue
             lo = org + nd["qlo"][:, c].astype(np.float64) * scale
             hi = org + nd["qhi"][:, c].astype(np.float64) * scale
-            if plo is not None:  # nested inside the parent's box for this node (up to quantisation rounding)
-                eps = 1e-6 * (1.0 + np.abs(phi).max())
-                assert np.all(lo >= plo - eps) and np.all(hi <= phi + eps)
+            if plo is not None:
+                # nested inside the box the parent stores for this node, up to one step of this node's
+                # own (finer) quantisation grid: both boxes round the same true box outwards
+                assert np.all(lo >= plo - scale) and np.all(hi <= phi + scale)
             if ref & LEAF:
                 first, cnt = ref & 0x0FFFFFFF, ((ref >> 28) & 7) + 1
                 assert 1 <= cnt <= 4 and first + cnt <= len(tris)

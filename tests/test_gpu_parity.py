@@ -79,8 +79,9 @@ def test_config0_cornell_512_16spp_depth8_image_bit_exact(rt, pa, cornell, ocorn
     want, rays = ocornell.render(view, proj, W, H, frames=2, spp_per_frame=8, max_depth=8, seed=0)
     assert rt.stats().rays_total == rays
     assert np.array_equal(bits(img), bits(want)), float(np.abs(img - want).max())
-    # statistical sanity of the converging picture: left wall red, right wall green (reference materials)
-    assert img[256, 40, 0] > img[256, 40, 1] and img[256, 470, 1] > img[256, 470, 0]
+    # sanity of the converging picture: this Cornell box has its green wall at x = -1 (image left) and
+    # the red one at x = +1 (image right) -- cornell.obj faces `usemtl green` / `usemtl red`
+    assert img[256, 40, 1] > img[256, 40, 0] and img[256, 470, 0] > img[256, 470, 1]
 
 
 def test_reference_constants_800x600_frame(rt, pa, cornell, ocornell):
