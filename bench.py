@@ -154,14 +154,17 @@ def main():
     if rank == 0:
         mrays = rays_all / dt_max / 1e6
         total_spp = a.steps * S * world
-        # dominant kernel: k_extend.  Algorithmic bytes per ray it must move:
-        # 32 B ray record read + 16 B hit record written + nodes*64 B + triangles*48 B.
-        bytes_per_ray_extend = 48.0 + nodes_per_ray * 64.0 + tris_per_ray * 48.0
+        # dominant kernel: k_extend.  Algorithmic HBM bytes per ray: 32 B ray record read
+        # + 16 B hit record written; the scene (2 KB for Cornell) is read once per launch.  Node/triangle
+        # fetches (nodes*64 + tris*48 B/ray) are cache traffic on this scene and reported separately.
+        scene_bytes = st.bvh_nodes * 64.0 + st.bvh_tris * 48.0
+        bytes_per_ray_extend = 48.0
+        cache_bytes_per_ray = nodes_per_ray * 64.0 + tris_per_ray * 48.0
         # whole-step figure of SURVEY.md 8(d): 160 B queue traffic + traversal + 172 B closest-hit gather
         bytes_per_ray_step = 160.0 + nodes_per_ray * 64.0 + tris_per_ray * 48.0 + 172.0 * p_hit
         ext_ms = st.extend_ms_total / max(1, st.extend_launches)
         rays_per_launch = rays_local / max(1, st.extend_launches)
-        achieved = (rays_per_launch * bytes_per_ray_extend) / (ext_ms * 1e-3) / 1e9 if ext_ms > 0 else 0.0
+        achieved = (rays_per_launch * bytes_per_ray_extend + scene_bytes) / (ext_ms * 1e-3) / 1e9 if ext_ms > 0 else 0.0
         traffic = None
         tpath = os.path.join(ROOT, "profiles", "traffic_extend.json")
         if os.path.exists(tpath):
@@ -183,7 +186,12 @@ def main():
             "roofline": {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic, "kernel": "k_extend",
                          "launch_ms": round(ext_ms, 4), "rays_per_launch": rays_per_launch,
-                         "bytes_per_ray": round(bytes_per_ray_extend, 2), "nodes_per_ray": round(nodes_per_ray, 3),
+                         "bytes_per_ray": round(bytes_per_ray_extend, 2),
+                         "cache_served_bytes_per_ray": round(cache_bytes_per_ray, 2),
+                         "cache_served_gbs": round(rays_per_launch * cache_bytes_per_ray / (ext_ms * 1e-3) / 1e9, 1)
+                         if ext_ms > 0 else 0.0,
+                         "extend_mrays_per_s": round(rays_per_launch / (ext_ms * 1e-3) / 1e6, 1) if ext_ms > 0 else 0.0,
+                         "nodes_per_ray": round(nodes_per_ray, 3),
                          "tris_per_ray": round(tris_per_ray, 3), "p_hit": round(p_hit, 4)},
             "roofline_step": {"bytes_per_ray": round(bytes_per_ray_step, 2),
                               "achieved": round(mrays / world * 1e6 * bytes_per_ray_step / 1e9, 2), "unit": "GB/s",
