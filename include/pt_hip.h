@@ -109,6 +109,7 @@ int pt_upload_scene(pt_ctx *ctx, const PtVertex *vertices, uint32_t n_vertices, 
 
 #define PT_ACCEL_BVH4 0         /* LBVH (Morton + LDS radix sort) collapsed to a quantised BVH4 */
 #define PT_ACCEL_BRUTE_FORCE 1  /* no hierarchy: every ray tests every triangle (parity/debug mode) */
+#define PT_ACCEL_LEAF_SIZE(n) ((n) << 8) /* OR into flags: at most n (1..8) triangles per leaf; 0 = default */
 
 /* VulkanRaytracing::buildBlas + buildTlas (VulkanRaytracing.cpp:147-262,448-527): what the
  * Vulkan driver did inside vkCmdBuildAccelerationStructuresKHR.  One BLAS, one identity
@@ -140,6 +141,13 @@ int pt_set_frame_schedule(pt_ctx *ctx, uint32_t first, uint32_t stride);
 #define PT_ACCUM_MEAN 0  /* running mean, mix(old,new,1/(frame+1)): raytrace.rgen:88-95 */
 #define PT_ACCUM_SUM 1   /* raw per-frame sums (exact, order-independent multi-GPU reduce) */
 int pt_set_accum_mode(pt_ctx *ctx, int mode);
+
+/* How one dispatch is executed on the device (no reference counterpart; results are bit-identical):
+ * FUSED (default) = one persistent kernel per bounce (traverse + shade + compact, lanes refilled in
+ * flight); SPLIT = the classic wavefront pair k_extend / k_shade with the hit records in HBM. */
+#define PT_PIPELINE_FUSED 0
+#define PT_PIPELINE_SPLIT 1
+int pt_set_pipeline(pt_ctx *ctx, int mode);
 
 /* VulkanRaytracing::raytrace (VulkanRaytracing.cpp:868-901): ++frame, dispatch W x H x 1,
  * accumulate; a no-op once frame >= max_frames.  Asynchronous. */

@@ -18,6 +18,8 @@ PT_ACCUM_MEAN = 0
 PT_ACCUM_SUM = 1
 PT_PROFILE_KERNELS = 1
 PT_PROFILE_TRAVERSAL = 2
+PT_PIPELINE_FUSED = 0
+PT_PIPELINE_SPLIT = 1
 
 
 class PtStats(C.Structure):
@@ -44,6 +46,7 @@ SYMBOLS = {
     "pt_set_params": (_i, [_vp, _i, _i, _f, _f, _u32, _i]),
     "pt_set_frame_schedule": (_i, [_vp, _u32, _u32]),
     "pt_set_accum_mode": (_i, [_vp, _i]),
+    "pt_set_pipeline": (_i, [_vp, _i]),
     "pt_render_frame": (_i, [_vp]),
     "pt_render_frames": (_i, [_vp, _i]),
     "pt_reset_accumulation": (_i, [_vp]),

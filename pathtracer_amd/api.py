@@ -15,7 +15,7 @@ import numpy as np
 
 from . import _lib
 from ._lib import (PT_ACCEL_BRUTE_FORCE, PT_ACCEL_BVH4, PT_ACCUM_MEAN, PT_ACCUM_SUM, PT_NO_HIT, PT_PROFILE_KERNELS,
-                   PT_PROFILE_TRAVERSAL, PtStats)
+                   PT_PROFILE_TRAVERSAL, PT_PIPELINE_FUSED, PT_PIPELINE_SPLIT, PtStats)
 
 HIT_DTYPE = np.dtype([("t", np.float32), ("u", np.float32), ("v", np.float32), ("prim", np.uint32)])
 NODE_DTYPE = np.dtype([("origin", np.float32, 3), ("exps", np.uint32), ("child", np.uint32, 4),
@@ -189,6 +189,9 @@ class HipRaytracing:
     def setAccumMode(self, mode):
         self._check(self._L.pt_set_accum_mode(self._ctx, mode))
 
+    def setPipeline(self, mode):
+        self._check(self._L.pt_set_pipeline(self._ctx, mode))
+
     def raytrace(self, frames: int = 1):
         """VulkanRaytracing::raytrace (VulkanRaytracing.cpp:868-901), `frames` times.  Asynchronous."""
         self._check(self._L.pt_render_frames(self._ctx, frames))
@@ -276,4 +279,4 @@ class HipRaytracing:
 
 __all__ = ["HipRaytracing", "PathTracerError", "Scene", "load_obj", "look_at", "perspective", "inverse4",
            "reference_camera", "HIT_DTYPE", "NODE_DTYPE", "TRI_DTYPE", "PT_ACCEL_BVH4", "PT_ACCEL_BRUTE_FORCE",
-           "PT_ACCUM_MEAN", "PT_ACCUM_SUM", "PT_NO_HIT", "PT_PROFILE_KERNELS", "PT_PROFILE_TRAVERSAL", "PtStats"]
+           "PT_ACCUM_MEAN", "PT_ACCUM_SUM", "PT_NO_HIT", "PT_PROFILE_KERNELS", "PT_PROFILE_TRAVERSAL", "PT_PIPELINE_FUSED", "PT_PIPELINE_SPLIT", "PtStats"]

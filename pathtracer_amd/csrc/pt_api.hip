@@ -6,6 +6,7 @@
 
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -50,6 +51,7 @@ struct pt_ctx
 	uint32_t seed = 0;
 	uint32_t firstFrame = 0, frameStride = 1;
 	int accumMode = PT_ACCUM_MEAN;
+	int pipeline = PT_PIPELINE_FUSED;
 	int frame = -1;  // m_pcRay.frame
 	bool haveCamera = false;
 	PtCamera cam;
@@ -99,6 +101,8 @@ void freeQueues(pt_ctx *c)
 	}
 	hipFree(c->q.hits);
 	hipFree(c->q.rad);
+	hipFree(c->q.chunkCount[0]);
+	hipFree(c->q.chunkCount[1]);
 	c->q = PtQueues();
 	c->queueCap = 0;
 }
@@ -133,11 +137,15 @@ int ensureQueues(pt_ctx *c, size_t records)
 	if (records <= c->queueCap) return PT_OK;
 	freeQueues(c);
 	const size_t bytes = records * sizeof(float4);
+	// the fused pipeline allocates output chunks densely: at most one partially filled chunk per wave
+	const size_t chunks = (records + PT_CHUNK - 1) / PT_CHUNK + c->cfg.bounceWaves;
+	const size_t qbytes = chunks * PT_CHUNK * sizeof(float4);
 	for (int i = 0; i < 2; ++i)
 	{
-		PT_HIP(c, hipMalloc(&c->q.rayO[i], bytes));
-		PT_HIP(c, hipMalloc(&c->q.rayD[i], bytes));
-		PT_HIP(c, hipMalloc(&c->q.thr[i], bytes));
+		PT_HIP(c, hipMalloc(&c->q.rayO[i], qbytes));
+		PT_HIP(c, hipMalloc(&c->q.rayD[i], qbytes));
+		PT_HIP(c, hipMalloc(&c->q.thr[i], qbytes));
+		PT_HIP(c, hipMalloc(&c->q.chunkCount[i], chunks * sizeof(uint32_t)));
 	}
 	PT_HIP(c, hipMalloc(&c->q.hits, bytes));
 	PT_HIP(c, hipMalloc(&c->q.rad, bytes));
@@ -208,7 +216,7 @@ int checkReady(pt_ctx *c, bool needImage)
 // Traces the rays in q.rayO[0]/q.rayD[0][0..n) into q.hits (debug entry points).
 int traceQueue0(pt_ctx *c, uint32_t n, float tmin, float tmax)
 {
-	ptLaunchFrameBegin(c->counters, n, c->stream);
+	ptLaunchFrameBegin(c->counters, n, 0, c->stream);
 	ptLaunchExtend(sceneDev(c), c->brute, &c->counters->count[0], &c->counters->headExtend[0], c->q.rayO[0],
 	               c->q.rayD[0], c->q.hits, tmin, tmax, c->cfg, nullptr, c->stream);
 	PT_HIP(c, hipGetLastError());
@@ -251,8 +259,24 @@ extern "C" pt_ctx *pt_create(int device)
 	ok = ok && hipMalloc(&c->counters, sizeof(PtFrameCounters)) == hipSuccess;
 	ok = ok && hipMalloc(&c->dStats, 5 * sizeof(unsigned long long)) == hipSuccess;
 	ok = ok && hipMemset(c->dStats, 0, 5 * sizeof(unsigned long long)) == hipSuccess;
-	c->cfg.persistentBlocks = (uint32_t)c->numCUs * 4u;
+	// persistent grid: blocks of 256 threads per CU (tuning knob PT_BLOCKS_PER_CU, default 4)
+	int blocksPerCU = 4;
+	if (const char *e = getenv("PT_BLOCKS_PER_CU"))
+	{
+		int v = atoi(e);
+		if (v >= 1 && v <= 8) blocksPerCU = v;
+	}
+	c->cfg.persistentBlocks = (uint32_t)c->numCUs * (uint32_t)blocksPerCU;
+	// fused kernel: single-wave blocks, 10 KB of LDS each -> 16 per CU (tuning knob PT_BOUNCE_WAVES_PER_CU)
+	int wavesPerCU = 16;
+	if (const char *e = getenv("PT_BOUNCE_WAVES_PER_CU"))
+	{
+		int v = atoi(e);
+		if (v >= 1 && v <= 16) wavesPerCU = v;
+	}
+	c->cfg.bounceWaves = (uint32_t)c->numCUs * (uint32_t)wavesPerCU;
 	c->cfg.spillStride = c->cfg.persistentBlocks * 256u;
+	if (c->cfg.bounceWaves * 64u > c->cfg.spillStride) c->cfg.spillStride = c->cfg.bounceWaves * 64u;
 	ok = ok && hipMalloc(&c->cfg.spill, sizeof(uint32_t) * (size_t)c->cfg.spillStride * PT_SPILL_STACK) == hipSuccess;
 	if (!ok)
 	{
@@ -343,14 +367,16 @@ extern "C" int pt_build_accel(pt_ctx *c, int flags)
 {
 	if (!c) return fail(nullptr, PT_EINVAL, "null context");
 	if (!c->haveScene) return fail(c, PT_EINVAL, "pt_build_accel: no scene uploaded");
-	if (flags != PT_ACCEL_BVH4 && flags != PT_ACCEL_BRUTE_FORCE) return fail(c, PT_EINVAL, "pt_build_accel: bad flags %d", flags);
+	const int mode = flags & 0xFF, leafMax = (flags >> 8) & 0xF;
+	if ((mode != PT_ACCEL_BVH4 && mode != PT_ACCEL_BRUTE_FORCE) || (flags & ~0xFFF) || leafMax > 8)
+		return fail(c, PT_EINVAL, "pt_build_accel: bad flags 0x%x", flags);
 	PT_HIP(c, hipSetDevice(c->device));
 	PT_HIP(c, hipStreamSynchronize(c->stream));
 	freeAccel(c);
-	c->brute = (flags == PT_ACCEL_BRUTE_FORCE);
+	c->brute = (mode == PT_ACCEL_BRUTE_FORCE);
 	// The Morton codes / sorted order / BVH are built in both modes (the debug entry points read
 	// them); brute-force mode just does not traverse the hierarchy.
-	PtBuildInput in = { c->dVerts, c->dIndices, c->nIdx / 3 };
+	PtBuildInput in = { c->dVerts, c->dIndices, c->nIdx / 3, leafMax };
 	hipEvent_t a = getEvent(c), b = getEvent(c);
 	hipEventRecord(a, c->stream);
 	hipError_t e = ptBuildBvh4(in, c->accel, c->stream);
@@ -448,7 +474,9 @@ extern "C" int pt_render_frame(pt_ctx *c)
 	const uint32_t gframe = c->firstFrame + (uint32_t)c->frame * c->frameStride;
 	hipStream_t s = c->stream;
 	PtSceneDev sc = sceneDev(c);
-	ptLaunchFrameBegin(c->counters, (uint32_t)nPaths, s);
+	const bool fused = (c->pipeline == PT_PIPELINE_FUSED) && !c->brute;
+	unsigned long long *trav = (c->profiling & PT_PROFILE_TRAVERSAL) ? c->dStats + 2 : nullptr;
+	ptLaunchFrameBegin(c->counters, (uint32_t)nPaths, fused ? 1 : 0, s);
 	ptLaunchGenerate(c->cam, c->W, c->H, (uint32_t)c->spp, c->seed + gframe, gframe == 0, c->q, s);
 	int in = 0;
 	for (int d = 0; d < c->maxDepth; ++d)
@@ -461,11 +489,20 @@ extern "C" int pt_render_frame(pt_ctx *c)
 			e2 = getEvent(c);
 			hipEventRecord(e0, s);
 		}
-		ptLaunchExtend(sc, c->brute, &c->counters->count[d], &c->counters->headExtend[d], c->q.rayO[in], c->q.rayD[in],
-		               c->q.hits, c->tmin, c->tmax, c->cfg, (c->profiling & PT_PROFILE_TRAVERSAL) ? c->dStats + 2 : nullptr, s);
-		if (e1) hipEventRecord(e1, s);
-		ptLaunchShade(sc, c->dPrimEmissive, &c->counters->count[d], &c->counters->headShade[d], c->q, in,
-		              &c->counters->count[d + 1], d == c->maxDepth - 1, c->cfg, s);
+		if (fused)
+		{
+			ptLaunchBounce(sc, c->q, in, c->counters, d, d == 0 ? (uint32_t)nPaths : 0u, c->tmin, c->tmax,
+			               d == c->maxDepth - 1, c->cfg, trav, s);
+			if (e1) hipEventRecord(e1, s);
+		}
+		else
+		{
+			ptLaunchExtend(sc, c->brute, &c->counters->count[d], &c->counters->headExtend[d], c->q.rayO[in],
+			               c->q.rayD[in], c->q.hits, c->tmin, c->tmax, c->cfg, trav, s);
+			if (e1) hipEventRecord(e1, s);
+			ptLaunchShade(sc, c->dPrimEmissive, &c->counters->count[d], &c->counters->headShade[d], c->q, in,
+			              &c->counters->count[d + 1], d == c->maxDepth - 1, c->cfg, s);
+		}
 		if (e2)
 		{
 			hipEventRecord(e2, s);
@@ -477,6 +514,14 @@ extern "C" int pt_render_frame(pt_ctx *c)
 	ptLaunchFrameEnd(c->counters, c->maxDepth, c->dStats, s);
 	PT_HIP(c, hipGetLastError());
 	c->framesRendered++;
+	return PT_OK;
+}
+
+extern "C" int pt_set_pipeline(pt_ctx *c, int mode)
+{
+	if (!c) return fail(nullptr, PT_EINVAL, "null context");
+	if (mode != PT_PIPELINE_FUSED && mode != PT_PIPELINE_SPLIT) return fail(c, PT_EINVAL, "pt_set_pipeline: bad mode %d", mode);
+	c->pipeline = mode;
 	return PT_OK;
 }
 

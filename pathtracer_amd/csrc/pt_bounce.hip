@@ -1,0 +1,403 @@
+// k_bounce: one bounce of every queued path in ONE persistent kernel -- traceRayEXT
+// (raytrace.rgen:65-76) + raytrace.rchit / raytrace.rmiss + the throughput update of
+// raytrace.rgen:78-79 -- with stream compaction into the next bounce's queue.
+//
+// Why one kernel.  Measured on MI355X (profiles/r01a_*): the split extend/shade pair spends its
+// time in VALU at ~34 % lane utilisation (lanes of a wave finish their traversal at different
+// times) and the shade kernel is a pure HBM round trip of the hit and ray records.  Here
+//   * every wave is persistent and refills lanes the moment they finish ("in-wave wavefront"):
+//     rays are PREPARED 64 at a time at full utilisation (coalesced queue read, shear constants,
+//     reciprocal direction) into an LDS staging area, idle lanes pick prepared rays up by ballot
+//     rank, finished lanes park their hit in an LDS ring, and the ring is SHADED 64 at a time at
+//     full utilisation -- only the traversal loop itself runs with partially filled waves;
+//   * the hit record never goes to HBM, the ray record is read once;
+//   * compaction costs no per-batch atomics: the queue is a sequence of 1024-record chunks with
+//     a count each.  A wave claims input chunks with one atomic per chunk and allocates output
+//     chunks with one atomic per 1024 survivors; survivors are packed by ballot + prefix popcount.
+// All arithmetic that reaches a result is the shared specification of pt_device_common.h, so
+// images stay bit-identical to the split pipeline and to the CPU oracle.
+#include "pt_trace.h"
+
+namespace
+{
+constexpr int kStackLds = 12;  // traversal stack entries per lane held in LDS; deeper ones spill to global
+constexpr int kInFields = 13;  // ox oy oz ix iy iz Sx Sy Sz kpack seed id rayIdx
+constexpr int kDoneFields = 7; // V W det prim seed id rayIdx
+constexpr int kDoneRing = 128;
+
+__device__ __forceinline__ uint32_t popc64(unsigned long long m) { return (uint32_t)__popcll(m); }
+
+template <bool kStats>
+__global__ void __launch_bounds__(PT_WAVE)
+    k_bounce(PtSceneDev sc, const float4 *__restrict__ rayOIn, const float4 *__restrict__ rayDIn,
+             const float4 *__restrict__ thrIn, float4 *__restrict__ rayOOut, float4 *__restrict__ rayDOut,
+             float4 *__restrict__ thrOut, const uint32_t *__restrict__ chunkCountIn, uint32_t *__restrict__ chunkCountOut,
+             const uint32_t *numChunksInPtr, uint32_t *chunkHead, uint32_t *numChunksOut, uint32_t *raysOut,
+             uint32_t denseN, float4 *__restrict__ rad, float tmin, float tmax, int lastBounce, uint32_t *spill,
+             uint32_t spillStride, unsigned long long *trav)
+{
+	__shared__ uint32_t sStack[kStackLds][PT_WAVE];
+	__shared__ uint32_t sIn[kInFields][PT_WAVE];
+	__shared__ uint32_t sDone[kDoneFields][kDoneRing];
+
+	const int lane = threadIdx.x;
+	const unsigned long long laneBit = 1ull << lane, lanesBelow = laneBit - 1ull;
+	const uint32_t numChunksIn = *numChunksInPtr;
+	uint32_t *mySpill = spill + (size_t)blockIdx.x * PT_WAVE + lane;
+
+	// wave-uniform cursors
+	uint32_t chunkBase = 0, chunkPos = 0, chunkCnt = 0;  // input chunk being consumed
+	bool exhausted = (numChunksIn == 0);
+	uint32_t inCount = 0, inPos = 0;                     // prepared rays in sIn
+	uint32_t doneHead = 0, doneTail = 0;                 // ring of finished rays
+	uint32_t outChunk = 0xFFFFFFFFu, outPos = PT_CHUNK;  // output chunk being filled
+	uint32_t raysFetched = 0;
+	uint32_t nodeFetches = 0, triTests = 0, nHits = 0;
+
+	// per-lane ray state
+	float ox = 0, oy = 0, oz = 0, ix = 0, iy = 0, iz = 0, Sx = 0, Sy = 0, Sz = 0;
+	uint32_t kpack = 0, seed = 0, id = 0, rayIdx = 0xFFFFFFFFu;
+	PtBest best = { tmax, PT_NO_HIT, 0.0f, 0.0f, 1.0f };
+	uint32_t cur = PT_TRAVERSAL_DONE;
+	int sp = 0;
+
+	// Shades up to 64 parked hits (ring entries doneHead .. doneHead+count) and emits the survivors.
+	auto flush = [&](uint32_t count) {
+		bool alive = false;
+		float3x no = { 0, 0, 0 }, nd = { 0, 0, 0 };
+		float tx = 0, ty = 0, tz = 0;
+		uint32_t nseed = 0, nid = 0;
+		if ((uint32_t)lane < count)
+		{
+			uint32_t e = (doneHead + lane) & (kDoneRing - 1);
+			uint32_t prim = sDone[3][e];
+			if (prim != PT_NO_HIT)  // rmiss: hitValue = 0, emission = 0, terminate -> nothing to do
+			{
+				float V = __uint_as_float(sDone[0][e]), W = __uint_as_float(sDone[1][e]), det = __uint_as_float(sDone[2][e]);
+				nseed = sDone[4][e];
+				nid = sDone[5][e];
+				uint32_t ridx = sDone[6][e];
+				float u = V / det, v = W / det;
+				float4 T = thrIn[ridx];
+				const float *mat;
+				pt_shade_hit(sc, prim, u, v, nseed, no, nd, mat);
+				float ex = mat[3], ey = mat[4], ez = mat[5];
+				if (ex != 0.0f || ey != 0.0f || ez != 0.0f)
+				{
+					// accumDepthHitValue += emission * curAttenuation (rgen:78); one thread owns a path
+					float4 L = rad[nid];
+					L.x += ex * T.x;
+					L.y += ey * T.y;
+					L.z += ez * T.z;
+					rad[nid] = L;
+				}
+				alive = !lastBounce && !((ex + ey) + ez > 0.0f);  // rchit:56-58
+				tx = T.x * mat[0];  // curAttenuation *= hitValue (rgen:79)
+				ty = T.y * mat[1];
+				tz = T.z * mat[2];
+				if (kStats) ++nHits;
+			}
+		}
+		doneHead += count;
+		unsigned long long am = __ballot(alive);
+		uint32_t total = popc64(am), rank = popc64(am & lanesBelow), emitted = 0;
+		while (emitted < total)
+		{
+			if (outPos == PT_CHUNK)
+			{
+				// close the full chunk, open a new one (one atomic per 1024 survivors)
+				uint32_t c = 0;
+				if (lane == 0)
+				{
+					if (outChunk != 0xFFFFFFFFu) chunkCountOut[outChunk] = PT_CHUNK;
+					c = atomicAdd(numChunksOut, 1u);
+				}
+				outChunk = __builtin_amdgcn_readfirstlane(c);
+				outPos = 0;
+			}
+			uint32_t take = total - emitted;
+			if (take > PT_CHUNK - outPos) take = PT_CHUNK - outPos;
+			if (alive && rank >= emitted && rank < emitted + take)
+			{
+				size_t dst = (size_t)outChunk * PT_CHUNK + outPos + (rank - emitted);
+				rayOOut[dst] = make_float4(no.x, no.y, no.z, __uint_as_float(nseed));
+				rayDOut[dst] = make_float4(nd.x, nd.y, nd.z, __uint_as_float(nid));
+				thrOut[dst] = make_float4(tx, ty, tz, 0.0f);
+			}
+			outPos += take;
+			emitted += take;
+		}
+	};
+
+	for (;;)
+	{
+		// ------------------------------------------------------------------ A: refill idle lanes ----
+		unsigned long long idle = __ballot(cur == PT_TRAVERSAL_DONE);
+		while (idle)
+		{
+			if (inPos == inCount)
+			{
+				if (exhausted) break;
+				if (chunkPos == chunkCnt)
+				{
+					uint32_t c = 0;
+					if (lane == 0) c = atomicAdd(chunkHead, 1u);
+					c = __builtin_amdgcn_readfirstlane(c);
+					if (c >= numChunksIn)
+					{
+						exhausted = true;
+						break;
+					}
+					uint32_t cnt;
+					if (denseN)
+					{
+						uint32_t rem = denseN - c * PT_CHUNK;
+						cnt = rem < PT_CHUNK ? rem : PT_CHUNK;
+					}
+					else cnt = __builtin_amdgcn_readfirstlane(chunkCountIn[c]);
+					chunkBase = c * PT_CHUNK;
+					chunkPos = 0;
+					chunkCnt = cnt;
+					if (cnt == 0) continue;
+				}
+				// prepare the next (up to) 64 rays of the chunk at full utilisation
+				uint32_t n = chunkCnt - chunkPos;
+				if (n > PT_WAVE) n = PT_WAVE;
+				__syncthreads();  // all lanes are done reading the previous staging contents
+				if ((uint32_t)lane < n)
+				{
+					uint32_t ridx = chunkBase + chunkPos + lane;
+					float4 ro = rayOIn[ridx], rd = rayDIn[ridx];
+					float3x d = { rd.x, rd.y, rd.z };
+					PtRayShear rs = pt_ray_shear(d);
+					// box test only: zero components nudged so that 0 * inf cannot occur (interval stays huge)
+					float dcx = fabsf(d.x) > 1e-30f ? d.x : copysignf(1e-30f, d.x);
+					float dcy = fabsf(d.y) > 1e-30f ? d.y : copysignf(1e-30f, d.y);
+					float dcz = fabsf(d.z) > 1e-30f ? d.z : copysignf(1e-30f, d.z);
+					float rx = 1.0f / dcx, ry = 1.0f / dcy, rz = 1.0f / dcz;
+					uint32_t kp = (uint32_t)rs.kx | ((uint32_t)rs.ky << 2) | ((uint32_t)rs.kz << 4) | ((rx < 0.0f) ? 64u : 0u) |
+					              ((ry < 0.0f) ? 128u : 0u) | ((rz < 0.0f) ? 256u : 0u);
+					sIn[0][lane] = __float_as_uint(ro.x);
+					sIn[1][lane] = __float_as_uint(ro.y);
+					sIn[2][lane] = __float_as_uint(ro.z);
+					sIn[3][lane] = __float_as_uint(rx);
+					sIn[4][lane] = __float_as_uint(ry);
+					sIn[5][lane] = __float_as_uint(rz);
+					sIn[6][lane] = __float_as_uint(rs.Sx);
+					sIn[7][lane] = __float_as_uint(rs.Sy);
+					sIn[8][lane] = __float_as_uint(rs.Sz);
+					sIn[9][lane] = kp;
+					sIn[10][lane] = __float_as_uint(ro.w);
+					sIn[11][lane] = __float_as_uint(rd.w);
+					sIn[12][lane] = ridx;
+				}
+				__syncthreads();
+				chunkPos += n;
+				inCount = n;
+				inPos = 0;
+				raysFetched += n;
+			}
+			uint32_t avail = inCount - inPos, want = popc64(idle);
+			uint32_t n = want < avail ? want : avail;
+			uint32_t rank = popc64(idle & lanesBelow);
+			bool take = (idle & laneBit) && rank < n;
+			if (take)
+			{
+				uint32_t s = inPos + rank;
+				ox = __uint_as_float(sIn[0][s]);
+				oy = __uint_as_float(sIn[1][s]);
+				oz = __uint_as_float(sIn[2][s]);
+				ix = __uint_as_float(sIn[3][s]);
+				iy = __uint_as_float(sIn[4][s]);
+				iz = __uint_as_float(sIn[5][s]);
+				Sx = __uint_as_float(sIn[6][s]);
+				Sy = __uint_as_float(sIn[7][s]);
+				Sz = __uint_as_float(sIn[8][s]);
+				kpack = sIn[9][s];
+				seed = sIn[10][s];
+				id = sIn[11][s];
+				rayIdx = sIn[12][s];
+				best.t = tmax;
+				best.prim = PT_NO_HIT;
+				best.V = 0.0f;
+				best.W = 0.0f;
+				best.det = 1.0f;
+				sp = 0;
+				cur = sc.nNodes ? 0u : PT_TRAVERSAL_DONE;
+			}
+			inPos += n;
+			idle &= ~__ballot(take);
+		}
+		unsigned long long hasRay = __ballot(rayIdx != 0xFFFFFFFFu);
+		if (!hasRay) break;  // input exhausted and every lane retired
+
+		// ------------------------------------------------------------------ B: traverse ----
+		// inner nodes: every lane that sits on one steps together ...
+		while (!(cur & PT_LEAF_FLAG))
+		{
+			if (kStats) ++nodeFetches;
+			const uint4 *np = reinterpret_cast<const uint4 *>(sc.nodes + cur);
+			uint4 n0 = np[0], n1 = np[1], n2 = np[2], n3 = np[3];
+			float sx = __uint_as_float((n0.w & 0xFFu) << 23), sy = __uint_as_float(((n0.w >> 8) & 0xFFu) << 23),
+			      sz = __uint_as_float(((n0.w >> 16) & 0xFFu) << 23);
+			float ax = sx * ix, ay = sy * iy, az = sz * iz;
+			float bx = (__uint_as_float(n0.x) - ox) * ix, by = (__uint_as_float(n0.y) - oy) * iy,
+			      bz = (__uint_as_float(n0.z) - oz) * iz;
+			const bool negx = kpack & 64u, negy = kpack & 128u, negz = kpack & 256u;
+			// n2 = qlo[0..2], qhi[0]; n3 = qhi[1..2], pad
+			uint32_t nqx = negx ? n2.w : n2.x, fqx = negx ? n2.x : n2.w;
+			uint32_t nqy = negy ? n3.x : n2.y, fqy = negy ? n2.y : n3.x;
+			uint32_t nqz = negz ? n3.y : n2.z, fqz = negz ? n2.z : n3.y;
+			uint32_t refs[4] = { n1.x, n1.y, n1.z, n1.w };
+			uint32_t key[4];
+#pragma unroll
+			for (int c = 0; c < 4; ++c)
+			{
+				float tnx = __builtin_fmaf((float)((nqx >> (8 * c)) & 0xFFu), ax, bx);
+				float tny = __builtin_fmaf((float)((nqy >> (8 * c)) & 0xFFu), ay, by);
+				float tnz = __builtin_fmaf((float)((nqz >> (8 * c)) & 0xFFu), az, bz);
+				float tfx = __builtin_fmaf((float)((fqx >> (8 * c)) & 0xFFu), ax, bx);
+				float tfy = __builtin_fmaf((float)((fqy >> (8 * c)) & 0xFFu), ay, by);
+				float tfz = __builtin_fmaf((float)((fqz >> (8 * c)) & 0xFFu), az, bz);
+				float tn = fmaxf(fmaxf(tnx, tny), fmaxf(tnz, tmin));
+				float tf = fminf(fminf(tfx, tfy), fminf(tfz, best.t));
+				bool hit = (tn <= tf * 1.000001f) && (refs[c] != PT_EMPTY_CHILD);
+				key[c] = hit ? ((__float_as_uint(tn) & ~3u) | (uint32_t)c) : 0xFFFFFFFFu;
+			}
+#define PT_CE(a, b)                         \
+	{                                       \
+		uint32_t lo_ = min(key[a], key[b]); \
+		uint32_t hi_ = max(key[a], key[b]); \
+		key[a] = lo_;                       \
+		key[b] = hi_;                       \
+	}
+			PT_CE(0, 1) PT_CE(2, 3) PT_CE(0, 2) PT_CE(1, 3) PT_CE(1, 2)
+#undef PT_CE
+#define PT_REF(k) ((k & 2u) ? ((k & 1u) ? refs[3] : refs[2]) : ((k & 1u) ? refs[1] : refs[0]))
+#define PT_PUSH(v)                                                                          \
+	{                                                                                       \
+		if (sp < kStackLds) sStack[sp][lane] = (v);                                         \
+		else if (sp < kStackLds + PT_SPILL_STACK) mySpill[(size_t)(sp - kStackLds) * spillStride] = (v); \
+		++sp;                                                                               \
+	}
+			if (key[3] != 0xFFFFFFFFu) PT_PUSH(PT_REF(key[3]));
+			if (key[2] != 0xFFFFFFFFu) PT_PUSH(PT_REF(key[2]));
+			if (key[1] != 0xFFFFFFFFu) PT_PUSH(PT_REF(key[1]));
+			if (key[0] != 0xFFFFFFFFu) cur = PT_REF(key[0]);
+			else
+			{
+				if (sp == 0) cur = PT_TRAVERSAL_DONE;
+				else
+				{
+					--sp;
+					cur = sp < kStackLds ? sStack[sp][lane]
+					                     : (sp < kStackLds + PT_SPILL_STACK ? mySpill[(size_t)(sp - kStackLds) * spillStride]
+					                                                        : PT_EMPTY_CHILD);
+				}
+			}
+#undef PT_REF
+#undef PT_PUSH
+		}
+		// ... then every lane that sits on a leaf
+		while ((cur & PT_LEAF_FLAG) && cur != PT_TRAVERSAL_DONE)
+		{
+			if (cur != PT_EMPTY_CHILD)
+			{
+				PtRayShear rs;
+				rs.kx = (int)(kpack & 3u);
+				rs.ky = (int)((kpack >> 2) & 3u);
+				rs.kz = (int)((kpack >> 4) & 3u);
+				rs.Sx = Sx;
+				rs.Sy = Sy;
+				rs.Sz = Sz;
+				float3x o = { ox, oy, oz };
+				uint32_t first = cur & 0x0FFFFFFFu;
+				uint32_t cnt = ((cur >> 28) & 7u) + 1u;
+				if (kStats) triTests += cnt;
+				for (uint32_t i = 0; i < cnt; ++i)
+				{
+					const float4 *tp = reinterpret_cast<const float4 *>(sc.tris + first + i);
+					float4 a = tp[0], b = tp[1], c = tp[2];
+					float3x p0 = { a.x, a.y, a.z }, p1 = { a.w, b.x, b.y }, p2 = { b.z, b.w, c.x };
+					pt_tri_test(o, rs, tmin, p0, p1, p2, __float_as_uint(c.y), best);
+				}
+			}
+			if (sp == 0) cur = PT_TRAVERSAL_DONE;
+			else
+			{
+				--sp;
+				cur = sp < kStackLds ? sStack[sp][lane]
+				                     : (sp < kStackLds + PT_SPILL_STACK ? mySpill[(size_t)(sp - kStackLds) * spillStride]
+				                                                        : PT_EMPTY_CHILD);
+			}
+		}
+
+		// ------------------------------------------------------------------ C: retire finished lanes ----
+		bool fin = (rayIdx != 0xFFFFFFFFu) && (cur == PT_TRAVERSAL_DONE);
+		unsigned long long fm = __ballot(fin);
+		if (fm)
+		{
+			if (fin)
+			{
+				uint32_t e = (doneTail + popc64(fm & lanesBelow)) & (kDoneRing - 1);
+				sDone[0][e] = __float_as_uint(best.V);
+				sDone[1][e] = __float_as_uint(best.W);
+				sDone[2][e] = __float_as_uint(best.det);
+				sDone[3][e] = best.prim;
+				sDone[4][e] = seed;
+				sDone[5][e] = id;
+				sDone[6][e] = rayIdx;
+				rayIdx = 0xFFFFFFFFu;
+			}
+			doneTail += popc64(fm);
+			if (doneTail - doneHead >= PT_WAVE)
+			{
+				__syncthreads();
+				flush(PT_WAVE);
+				__syncthreads();
+			}
+		}
+	}
+	// drain the ring
+	__syncthreads();
+	if (doneTail != doneHead) flush(doneTail - doneHead);
+	if (lane == 0)
+	{
+		if (outChunk != 0xFFFFFFFFu) chunkCountOut[outChunk] = outPos;
+		if (raysFetched) atomicAdd(raysOut, raysFetched);
+	}
+	if (kStats)
+	{
+		unsigned long long a = nodeFetches, b = triTests, c = nHits;
+#pragma unroll
+		for (int o = 32; o > 0; o >>= 1)
+		{
+			a += __shfl_xor(a, o);
+			b += __shfl_xor(b, o);
+			c += __shfl_xor(c, o);
+		}
+		if (lane == 0)
+		{
+			atomicAdd(&trav[0], a);
+			atomicAdd(&trav[1], b);
+			atomicAdd(&trav[2], c);
+		}
+	}
+}
+}  // namespace
+
+void ptLaunchBounce(const PtSceneDev &sc, const PtQueues &q, int in, PtFrameCounters *fc, int depth, uint32_t denseN,
+                    float tmin, float tmax, int lastBounce, const PtLaunchCfg &cfg, unsigned long long *travStats,
+                    hipStream_t s)
+{
+	const int out = in ^ 1;
+#define PT_BOUNCE(S)                                                                                                   \
+	k_bounce<S><<<cfg.bounceWaves, PT_WAVE, 0, s>>>(sc, q.rayO[in], q.rayD[in], q.thr[in], q.rayO[out], q.rayD[out],   \
+	                                                q.thr[out], q.chunkCount[in], q.chunkCount[out], &fc->numChunks[depth], \
+	                                                &fc->chunkHead[depth], &fc->numChunks[depth + 1], &fc->count[depth], \
+	                                                denseN, q.rad, tmin, tmax, lastBounce, cfg.spill, cfg.spillStride,   \
+	                                                travStats)
+	if (travStats) PT_BOUNCE(true);
+	else PT_BOUNCE(false);
+#undef PT_BOUNCE
+}

@@ -7,6 +7,7 @@ struct PtBuildInput
 	const PtVertex *vertices;  // device
 	const uint32_t *indices;   // device
 	uint32_t nTris;
+	int leafMax;  // triangles per leaf (1..PT_LEAF_MAX); 0 = PT_LEAF_DEFAULT
 };
 
 struct PtBuildOutput

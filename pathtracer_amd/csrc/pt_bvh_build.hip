@@ -388,7 +388,7 @@ __global__ void __launch_bounds__(kBlock)
     k_collapse_level(const CollapseTask *tasksIn, uint32_t nIn, CollapseTask *tasksOut, uint32_t *nOut, int n,
                      const int2 *children, const int2 *range, const float *boxes, const uint32_t *sortedPrim,
                      const PtVertex *verts, const uint32_t *indices, PtNode4 *nodes, uint32_t *nodeCount,
-                     PtTri48 *tris, uint32_t *triCount)
+                     PtTri48 *tris, uint32_t *triCount, int leafMax)
 {
 	uint32_t ti = blockIdx.x * kBlock + threadIdx.x;
 	if (ti >= nIn) return;
@@ -399,7 +399,7 @@ __global__ void __launch_bounds__(kBlock)
 	{
 		int f, l;
 		nodeRange(task.bvh2, n, range, f, l);
-		if (l - f + 1 <= PT_LEAF_MAX)
+		if (l - f + 1 <= leafMax)
 			slot[nSlots++] = task.bvh2;  // whole subtree is one leaf child
 		else
 		{
@@ -415,7 +415,7 @@ __global__ void __launch_bounds__(kBlock)
 				{
 					int f2, l2;
 					nodeRange(slot[s], n, range, f2, l2);
-					if (l2 - f2 + 1 <= PT_LEAF_MAX) continue;  // stays a leaf child
+					if (l2 - f2 + 1 <= leafMax) continue;  // stays a leaf child
 					float a = halfArea(boxes + 8 * (size_t)slot[s]);
 					if (a > bestArea)
 					{
@@ -499,7 +499,7 @@ __global__ void __launch_bounds__(kBlock)
 		int f, l;
 		nodeRange(slot[s], n, range, f, l);
 		int cnt = l - f + 1;
-		if (cnt <= PT_LEAF_MAX)
+		if (cnt <= leafMax)
 		{
 			uint32_t base = atomicAdd(triCount, (uint32_t)cnt);
 			for (int t = 0; t < cnt; ++t)
@@ -553,6 +553,7 @@ static inline uint32_t divUp(size_t a, size_t b) { return (uint32_t)((a + b - 1)
 hipError_t ptBuildBvh4(const PtBuildInput &in, PtBuildOutput &out, hipStream_t stream)
 {
 	const uint32_t n = in.nTris;
+	const int leafMax = in.leafMax < 1 ? PT_LEAF_DEFAULT : (in.leafMax > PT_LEAF_MAX ? PT_LEAF_MAX : in.leafMax);
 	out = PtBuildOutput();
 	if (n == 0) return hipSuccess;
 	if (n > 0x0FFFFFFFu) return hipErrorInvalidValue;
@@ -641,7 +642,7 @@ hipError_t ptBuildBvh4(const PtBuildInput &in, PtBuildOutput &out, hipStream_t s
 			++depth;
 			k_collapse_level<<<divUp(nIn, kBlock), kBlock, 0, stream>>>(tin, nIn, tout, counters + 2, (int)n, children,
 			                                                          range, boxes, vin, in.vertices, in.indices, nodes,
-			                                                          counters, tris, counters + 1);
+			                                                          counters, tris, counters + 1, leafMax);
 			uint32_t h[4];
 			err = hipMemcpyAsync(h, counters, sizeof(h), hipMemcpyDeviceToHost, stream);
 			TRY(hipStreamSynchronize(stream));

@@ -252,7 +252,8 @@ static_assert(sizeof(PtNode4) == 64, "PtNode4 must be 64 bytes");
 #define PT_LEAF_FLAG 0x80000000u
 #define PT_EMPTY_CHILD 0xFFFFFFFEu  // unused child slot (never reported as hit)
 #define PT_TRAVERSAL_DONE 0xFFFFFFFFu
-#define PT_LEAF_MAX 4
+#define PT_LEAF_MAX 8      // the leaf reference has 3 bits for (count - 1)
+#define PT_LEAF_DEFAULT 4
 
 // 48-byte leaf triangle: three 16-byte loads.  (v0.xyz, v1.x) (v1.yz, v2.xy) (v2.z, prim, -, -)
 struct __attribute__((aligned(16))) PtTri48
@@ -276,3 +277,27 @@ struct PtSceneDev
 	uint32_t nTris;
 	uint32_t nNodes;
 };
+
+// ---------------------------------------------------------------------- closest hit ----
+// raytrace.rchit:24-59 for one hit.  Returns the new ray, updates seed; mat = material record.
+__device__ __forceinline__ void pt_shade_hit(const PtSceneDev &sc, uint32_t prim, float u, float v, uint32_t &seed,
+                                         float3x &o, float3x &d, const float *&mat)
+{
+	mat = sc.materials[sc.matIndices[prim]].diffuse;
+	const float *v0 = sc.vertices[sc.indices[3 * (size_t)prim + 0]].pos;
+	const float *v1 = sc.vertices[sc.indices[3 * (size_t)prim + 1]].pos;
+	const float *v2 = sc.vertices[sc.indices[3 * (size_t)prim + 2]].pos;
+	float bx = (1.0f - u) - v, by = u, bz = v;
+	float3x N, P;
+	N.x = (v0[3] * bx + v1[3] * by) + v2[3] * bz;
+	N.y = (v0[4] * bx + v1[4] * by) + v2[4] * bz;
+	N.z = (v0[5] * bx + v1[5] * by) + v2[5] * bz;
+	P.x = (v0[0] * bx + v1[0] * by) + v2[0] * bz;
+	P.y = (v0[1] * bx + v1[1] * by) + v2[1] * bz;
+	P.z = (v0[2] * bx + v1[2] * by) + v2[2] * bz;
+	float3x Nn = pt_normalize(N);
+	float3x rv = pt_rnd_unit_vector(seed);
+	d = pt_normalize({ Nn.x + rv.x, Nn.y + rv.y, Nn.z + rv.z });
+	o = P;
+}
+

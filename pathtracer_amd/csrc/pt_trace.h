@@ -4,13 +4,16 @@
 
 #define PT_MAX_DEPTH 64     // upper bound for max_depth (reference: 20)
 #define PT_SPILL_STACK 72   // traversal stack entries per lane beyond the LDS-resident ones
+#define PT_CHUNK 1024u      // queue records per chunk (work-claim and compaction granularity)
 
 // Per-frame device counters, zeroed by k_frame_begin.  count[d] = rays queued for bounce d.
 struct PtFrameCounters
 {
-	uint32_t count[PT_MAX_DEPTH + 1];
+	uint32_t count[PT_MAX_DEPTH + 1];       // split pipeline: queue length; fused: rays traced at bounce d
 	uint32_t headExtend[PT_MAX_DEPTH + 1];
 	uint32_t headShade[PT_MAX_DEPTH + 1];
+	uint32_t numChunks[PT_MAX_DEPTH + 2];   // fused pipeline: chunks in the queue of bounce d
+	uint32_t chunkHead[PT_MAX_DEPTH + 1];   // fused pipeline: next input chunk to claim
 };
 
 // Path/ray queues in HBM (SoA float4 streams, capacity = W*H*spp_per_frame records each).
@@ -21,16 +24,18 @@ struct PtQueues
 	float4 *thr[2];   // (throughput.xyz, -)
 	float4 *hits;     // PtHit per queued ray
 	float4 *rad;      // radiance per path id (sample-major: id = sample*W*H + pixel)
+	uint32_t *chunkCount[2];  // fused pipeline: valid records at the front of each 1024-record chunk
 };
 
 struct PtLaunchCfg
 {
 	uint32_t persistentBlocks;  // grid of the persistent extend/shade kernels
 	uint32_t *spill;            // persistentBlocks*256*PT_SPILL_STACK words
-	uint32_t spillStride;       // persistentBlocks*256
+	uint32_t spillStride;       // lanes the spill strip is laid out for
+	uint32_t bounceWaves;       // grid of the fused k_bounce kernel (single-wave blocks)
 };
 
-void ptLaunchFrameBegin(PtFrameCounters *fc, uint32_t nPaths, hipStream_t s);
+void ptLaunchFrameBegin(PtFrameCounters *fc, uint32_t nPaths, int fused, hipStream_t s);
 void ptLaunchFrameEnd(const PtFrameCounters *fc, int depth, unsigned long long *stats, hipStream_t s);
 void ptLaunchGenerate(const PtCamera &cam, uint32_t W, uint32_t H, uint32_t spp, uint32_t seedWord, int centreJitter,
                       const PtQueues &q, hipStream_t s);
@@ -39,6 +44,11 @@ void ptLaunchExtend(const PtSceneDev &sc, bool brute, const uint32_t *count, uin
                     unsigned long long *travStats /* null = uninstrumented kernel */, hipStream_t s);
 void ptLaunchShade(const PtSceneDev &sc, const uint8_t *primEmissive, const uint32_t *count, uint32_t *head,
                    const PtQueues &q, int in, uint32_t *countOut, int lastBounce, const PtLaunchCfg &cfg, hipStream_t s);
+// Fused extend+shade+compact for bounce `depth`: reads queue `in`, writes queue `in^1`.  denseN != 0: the
+// input queue is the dense output of k_generate with denseN records (chunk counts implied).
+void ptLaunchBounce(const PtSceneDev &sc, const PtQueues &q, int in, PtFrameCounters *fc, int depth, uint32_t denseN,
+                    float tmin, float tmax, int lastBounce, const PtLaunchCfg &cfg, unsigned long long *travStats,
+                    hipStream_t s);
 void ptLaunchAccumulate(const PtQueues &q, uint32_t WH, uint32_t spp, float4 *image, uint32_t lframe, int mode,
                         hipStream_t s);
 void ptLaunchDebugRng(uint32_t n, const uint32_t *v0, const uint32_t *v1, uint32_t nSteps, uint32_t *outTea,

@@ -17,7 +17,7 @@
 namespace
 {
 constexpr int kBlock = 256;
-constexpr int kChunk = 1024;        // rays per work-queue claim (one atomic per wave per chunk)
+constexpr int kChunk = PT_CHUNK;    // rays per work-queue claim (one atomic per wave per chunk)
 constexpr int kLdsStack = 24;       // stack entries kept in LDS per lane; deeper entries spill to global
 
 struct Stack
@@ -58,9 +58,10 @@ __device__ __forceinline__ PtHit traverseBvh4(const PtSceneDev &sc, float3x o, f
 	const bool negx = inv.x < 0.0f, negy = inv.y < 0.0f, negz = inv.z < 0.0f;
 	st.sp = 0;
 	uint32_t cur = sc.nNodes ? 0u : PT_TRAVERSAL_DONE;
+	// while-while: all lanes that sit on an inner node step together, then all lanes on a leaf
 	while (cur != PT_TRAVERSAL_DONE)
 	{
-		if (!(cur & PT_LEAF_FLAG))
+		while (!(cur & PT_LEAF_FLAG))
 		{
 			if (kStats) ++nodeFetches;
 			const uint4 *np = reinterpret_cast<const uint4 *>(sc.nodes + cur);
@@ -107,12 +108,13 @@ __device__ __forceinline__ PtHit traverseBvh4(const PtSceneDev &sc, float3x o, f
 			cur = (key[0] != 0xFFFFFFFFu) ? PT_REF(key[0]) : st.pop();
 #undef PT_REF
 		}
-		else if (cur == PT_EMPTY_CHILD)
+		while ((cur & PT_LEAF_FLAG) && cur != PT_TRAVERSAL_DONE)
 		{
-			cur = st.pop();  // placeholder of an entry dropped on stack overflow
-		}
-		else
-		{
+			if (cur == PT_EMPTY_CHILD)
+			{
+				cur = st.pop();  // placeholder of an entry dropped on stack overflow
+				continue;
+			}
 			uint32_t first = cur & 0x0FFFFFFFu;
 			uint32_t cnt = ((cur >> 28) & 7u) + 1u;
 			if (kStats) triTests += cnt;
@@ -229,28 +231,6 @@ __global__ void __launch_bounds__(kBlock)
 }
 
 // --------------------------------------------------------------------------- shade ----
-// raytrace.rchit:24-59 for one hit.  Returns the new ray, updates seed; mat = material record.
-__device__ __forceinline__ void shadeHit(const PtSceneDev &sc, uint32_t prim, float u, float v, uint32_t &seed,
-                                         float3x &o, float3x &d, const float *&mat)
-{
-	mat = sc.materials[sc.matIndices[prim]].diffuse;
-	const float *v0 = sc.vertices[sc.indices[3 * (size_t)prim + 0]].pos;
-	const float *v1 = sc.vertices[sc.indices[3 * (size_t)prim + 1]].pos;
-	const float *v2 = sc.vertices[sc.indices[3 * (size_t)prim + 2]].pos;
-	float bx = (1.0f - u) - v, by = u, bz = v;
-	float3x N, P;
-	N.x = (v0[3] * bx + v1[3] * by) + v2[3] * bz;
-	N.y = (v0[4] * bx + v1[4] * by) + v2[4] * bz;
-	N.z = (v0[5] * bx + v1[5] * by) + v2[5] * bz;
-	P.x = (v0[0] * bx + v1[0] * by) + v2[0] * bz;
-	P.y = (v0[1] * bx + v1[1] * by) + v2[1] * bz;
-	P.z = (v0[2] * bx + v1[2] * by) + v2[2] * bz;
-	float3x Nn = pt_normalize(N);
-	float3x rv = pt_rnd_unit_vector(seed);
-	d = pt_normalize({ Nn.x + rv.x, Nn.y + rv.y, Nn.z + rv.z });
-	o = P;
-}
-
 __global__ void __launch_bounds__(kBlock)
     k_shade(PtSceneDev sc, const uint8_t *primEmissive, const uint32_t *count, uint32_t *head, const float4 *hits,
             const float4 *rayOIn, const float4 *rayDIn, const float4 *thrIn, float4 *rayOOut, float4 *rayDOut,
@@ -307,7 +287,7 @@ __global__ void __launch_bounds__(kBlock)
 					uint32_t id = __float_as_uint(rd.w);
 					float3x o, d;
 					const float *mat;
-					shadeHit(sc, prim, h.y, h.z, seed, o, d, mat);
+					pt_shade_hit(sc, prim, h.y, h.z, seed, o, d, mat);
 					float ex = mat[3], ey = mat[4], ez = mat[5];
 					if (ex != 0.0f || ey != 0.0f || ez != 0.0f)
 					{
@@ -366,12 +346,16 @@ __global__ void __launch_bounds__(kBlock)
 }
 
 // ------------------------------------------------------------------- frame counters ----
-__global__ void k_frame_begin(PtFrameCounters *fc, uint32_t nPaths)
+__global__ void k_frame_begin(PtFrameCounters *fc, uint32_t nPaths, int fused)
 {
 	uint32_t *w = reinterpret_cast<uint32_t *>(fc);
 	for (uint32_t i = threadIdx.x; i < sizeof(PtFrameCounters) / 4; i += blockDim.x) w[i] = 0;
 	__syncthreads();
-	if (threadIdx.x == 0) fc->count[0] = nPaths;
+	if (threadIdx.x == 0)
+	{
+		if (fused) fc->numChunks[0] = (nPaths + PT_CHUNK - 1) / PT_CHUNK;  // count[d] is summed by the waves
+		else fc->count[0] = nPaths;
+	}
 }
 
 __global__ void k_frame_end(const PtFrameCounters *fc, int depth, unsigned long long *stats)
@@ -436,7 +420,10 @@ __global__ void __launch_bounds__(kBlock) k_srgb8(const float4 *image, uint32_t 
 
 static inline uint32_t divUp(size_t a, size_t b) { return (uint32_t)((a + b - 1) / b); }
 
-void ptLaunchFrameBegin(PtFrameCounters *fc, uint32_t nPaths, hipStream_t s) { k_frame_begin<<<1, 256, 0, s>>>(fc, nPaths); }
+void ptLaunchFrameBegin(PtFrameCounters *fc, uint32_t nPaths, int fused, hipStream_t s)
+{
+	k_frame_begin<<<1, 256, 0, s>>>(fc, nPaths, fused);
+}
 
 void ptLaunchFrameEnd(const PtFrameCounters *fc, int depth, unsigned long long *stats, hipStream_t s)
 {
