@@ -45,6 +45,7 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample-frames", type=int, default=1)
     ap.add_argument("--out-image", default="")
+    ap.add_argument("--pipeline", choices=["fused", "split"], default="fused")
     return ap.parse_args()
 
 
@@ -73,7 +74,8 @@ def main():
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
 
     import pathtracer_amd as pa
-    from pathtracer_amd.api import PT_ACCUM_MEAN, PT_ACCUM_SUM, PT_PROFILE_KERNELS, PT_PROFILE_TRAVERSAL
+    from pathtracer_amd.api import (PT_ACCUM_MEAN, PT_ACCUM_SUM, PT_PIPELINE_FUSED, PT_PIPELINE_SPLIT, PT_PROFILE_KERNELS,
+                                    PT_PROFILE_TRAVERSAL)
     from pathtracer_amd import multigpu
 
     W, H, S, D = a.width, a.height, a.spp_per_frame, a.depth
@@ -88,6 +90,7 @@ def main():
     first, stride = multigpu.frame_schedule(rank, world)
     rt.setFrameSchedule(first=first, stride=stride)
     rt.setAccumMode(PT_ACCUM_SUM if world > 1 else PT_ACCUM_MEAN)
+    rt.setPipeline(PT_PIPELINE_FUSED if a.pipeline == "fused" else PT_PIPELINE_SPLIT)
 
     def barrier():
         rt.synchronize()
@@ -157,8 +160,16 @@ def main():
         # dominant kernel: k_extend.  Algorithmic HBM bytes per ray: 32 B ray record read
         # + 16 B hit record written; the scene (2 KB for Cornell) is read once per launch.  Node/triangle
         # fetches (nodes*64 + tris*48 B/ray) are cache traffic on this scene and reported separately.
-        scene_bytes = st.bvh_nodes * 64.0 + st.bvh_tris * 48.0
-        bytes_per_ray_extend = 48.0
+        # Fused pipeline (default): the dominant kernel is k_bounce = traverse + shade + compact; per ray it
+        # must read the 32 B ray record, the 16 B throughput record of every ray that hits (p_hit) and write
+        # a 48 B record for every survivor (p_alive); the hit record never leaves the chip.
+        scene_bytes = st.bvh_nodes * 64.0 + 3 * st.bvh_tris * 48.0
+        paths_total = float(W) * H * S * a.steps
+        p_alive = max(0.0, (rays_local - paths_total) / max(1.0, rays_local))  # rays of bounce >= 1 = survivors
+        if a.pipeline == "fused":
+            bytes_per_ray_extend = 32.0 + 16.0 * p_hit + 48.0 * p_alive
+        else:
+            bytes_per_ray_extend = 48.0
         cache_bytes_per_ray = nodes_per_ray * 64.0 + tris_per_ray * 48.0
         # whole-step figure of SURVEY.md 8(d): 160 B queue traffic + traversal + 172 B closest-hit gather
         bytes_per_ray_step = 160.0 + nodes_per_ray * 64.0 + tris_per_ray * 48.0 + 172.0 * p_hit
@@ -166,7 +177,7 @@ def main():
         rays_per_launch = rays_local / max(1, st.extend_launches)
         achieved = (rays_per_launch * bytes_per_ray_extend + scene_bytes) / (ext_ms * 1e-3) / 1e9 if ext_ms > 0 else 0.0
         traffic = None
-        tpath = os.path.join(ROOT, "profiles", "traffic_extend.json")
+        tpath = os.path.join(ROOT, "profiles", "traffic_bounce.json" if a.pipeline == "fused" else "traffic_extend.json")
         if os.path.exists(tpath):
             try:
                 with open(tpath) as f:
@@ -184,7 +195,8 @@ def main():
             "samples_per_px_per_s": round(total_spp / dt_max, 3),
             "rays_per_step_per_gpu": rays_local / a.steps,
             "roofline": {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic, "kernel": "k_extend",
+                         "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
+                         "kernel": "k_bounce" if a.pipeline == "fused" else "k_extend", "p_alive": round(p_alive, 4),
                          "launch_ms": round(ext_ms, 4), "rays_per_launch": rays_per_launch,
                          "bytes_per_ray": round(bytes_per_ray_extend, 2),
                          "cache_served_bytes_per_ray": round(cache_bytes_per_ray, 2),
@@ -197,8 +209,9 @@ def main():
                               "achieved": round(mrays / world * 1e6 * bytes_per_ray_step / 1e9, 2), "unit": "GB/s",
                               "frac": round(mrays / world * 1e6 * bytes_per_ray_step / 1e9 / HBM_PEAK_GBS, 5),
                               "queue_only_frac": round(mrays / world * 1e6 * 160.0 / 1e9 / HBM_PEAK_GBS, 5)},
-            "kernel_ms": {"extend_mean": round(ext_ms, 4),
+            "kernel_ms": {("bounce_mean" if a.pipeline == "fused" else "extend_mean"): round(ext_ms, 4),
                           "shade_mean": round(st.shade_ms_total / max(1, st.shade_launches), 4)},
+            "pipeline": a.pipeline,
             "bvh": {"nodes": st.bvh_nodes, "depth": st.bvh_depth, "tris": st.bvh_tris, "build_ms": round(st.build_ms, 3)},
         }
         if world == 1 and not a.no_cpu_baseline:

@@ -161,7 +161,7 @@ PtSceneDev sceneDev(const pt_ctx *c)
 	s.materials = c->dMats;
 	s.matIndices = c->dMatIdx;
 	s.nodes = c->accel.nodes;
-	s.tris = c->accel.tris;
+	s.tris = c->accel.tris;  // plane 0; plane r at tris + r * nTris
 	s.nTris = c->nIdx / 3;
 	s.nNodes = c->accel.nNodes;
 	return s;
@@ -731,6 +731,6 @@ extern "C" int pt_debug_read_bvh(pt_ctx *c, void *nodes, uint32_t *nNodes, void 
 	if (nodes && c->accel.nNodes)
 		PT_HIP(c, hipMemcpy(nodes, c->accel.nodes, sizeof(PtNode4) * (size_t)c->accel.nNodes, hipMemcpyDeviceToHost));
 	if (tris && c->accel.nTris)
-		PT_HIP(c, hipMemcpy(tris, c->accel.tris, sizeof(PtTri48) * (size_t)c->accel.nTris, hipMemcpyDeviceToHost));
+		PT_HIP(c, hipMemcpy(tris, c->accel.tris + 2 * (size_t)c->accel.nTris, sizeof(PtTri48) * (size_t)c->accel.nTris, hipMemcpyDeviceToHost));
 	return PT_OK;
 }

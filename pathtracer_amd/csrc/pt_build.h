@@ -13,7 +13,7 @@ struct PtBuildInput
 struct PtBuildOutput
 {
 	PtNode4 *nodes = nullptr;   // device, nNodes used
-	PtTri48 *tris = nullptr;    // device, nTris, leaf order
+	PtTri48 *tris = nullptr;    // device, 3 planes x nTris, leaf order; plane r = coordinates rotated to ((r+1)%3,(r+2)%3,r)
 	uint32_t *codes = nullptr;  // device, Morton code per primitive (primitive order)
 	uint32_t *order = nullptr;  // device, primitive ids sorted by (code, id)
 	uint32_t nNodes = 0, nTris = 0, depth = 0;

@@ -509,15 +509,21 @@ __global__ void __launch_bounds__(kBlock)
 				const float *p0 = verts[indices[3 * (size_t)prim + 0]].pos;
 				const float *p1 = verts[indices[3 * (size_t)prim + 1]].pos;
 				const float *p2 = verts[indices[3 * (size_t)prim + 2]].pos;
-				for (int a = 0; a < 3; ++a)
-				{
-					tr.v0[a] = p0[a];
-					tr.v1[a] = p1[a];
-					tr.v2[a] = p2[a];
-				}
 				tr.prim = prim;
 				tr.pad[0] = tr.pad[1] = 0;
-				tris[base + t] = tr;
+				// plane r holds the coordinates in the order ((r+1)%3, (r+2)%3, r): the watertight test of a ray
+				// whose dominant axis is r reads them without per-lane selects.  Plane 2 is the identity.
+				for (int r = 0; r < 3; ++r)
+				{
+					for (int a = 0; a < 3; ++a)
+					{
+						int src = (r + 1 + a) % 3;
+						tr.v0[a] = p0[src];
+						tr.v1[a] = p1[src];
+						tr.v2[a] = p2[src];
+					}
+					tris[(size_t)r * n + base + t] = tr;
+				}
 			}
 			node.child[s] = PT_LEAF_FLAG | ((uint32_t)(cnt - 1) << 28) | base;
 		}
@@ -596,7 +602,7 @@ hipError_t ptBuildBvh4(const PtBuildInput &in, PtBuildOutput &out, hipStream_t s
 	uint32_t *codes = nullptr, *order = nullptr;
 	float *cbounds = nullptr;
 	TRY(hipMalloc(&nodes, sizeof(PtNode4) * (size_t)n));  // a wide node has >= 2 children unless it is the root
-	TRY(hipMalloc(&tris, sizeof(PtTri48) * (size_t)n));
+	TRY(hipMalloc(&tris, 3 * sizeof(PtTri48) * (size_t)n));  // three axis-rotated planes
 	TRY(hipMalloc(&codes, 4 * (size_t)n));
 	TRY(hipMalloc(&order, 4 * (size_t)n));
 

@@ -253,7 +253,7 @@ static_assert(sizeof(PtNode4) == 64, "PtNode4 must be 64 bytes");
 #define PT_EMPTY_CHILD 0xFFFFFFFEu  // unused child slot (never reported as hit)
 #define PT_TRAVERSAL_DONE 0xFFFFFFFFu
 #define PT_LEAF_MAX 8      // the leaf reference has 3 bits for (count - 1)
-#define PT_LEAF_DEFAULT 4
+#define PT_LEAF_DEFAULT 2
 
 // 48-byte leaf triangle: three 16-byte loads.  (v0.xyz, v1.x) (v1.yz, v2.xy) (v2.z, prim, -, -)
 struct __attribute__((aligned(16))) PtTri48
