@@ -277,6 +277,8 @@ extern "C" pt_ctx *pt_create(int device)
 	c->cfg.bounceWaves = (uint32_t)c->numCUs * (uint32_t)wavesPerCU;
 	c->cfg.spillStride = c->cfg.persistentBlocks * 256u;
 	if (c->cfg.bounceWaves * 64u > c->cfg.spillStride) c->cfg.spillStride = c->cfg.bounceWaves * 64u;
+	ok = ok && hipMalloc(&c->cfg.waveRays, sizeof(uint32_t) * c->cfg.bounceWaves) == hipSuccess;
+	ok = ok && hipMemset(c->cfg.waveRays, 0, sizeof(uint32_t) * c->cfg.bounceWaves) == hipSuccess;
 	ok = ok && hipMalloc(&c->cfg.spill, sizeof(uint32_t) * (size_t)c->cfg.spillStride * PT_SPILL_STACK) == hipSuccess;
 	if (!ok)
 	{
@@ -300,6 +302,7 @@ extern "C" void pt_destroy(pt_ctx *c)
 	hipFree(c->counters);
 	hipFree(c->dStats);
 	hipFree(c->cfg.spill);
+	hipFree(c->cfg.waveRays);
 	if (c->ownStream) hipStreamDestroy(c->ownStream);
 	delete c;
 }
@@ -511,7 +514,7 @@ extern "C" int pt_render_frame(pt_ctx *c)
 		in ^= 1;
 	}
 	ptLaunchAccumulate(c->q, WH, (uint32_t)c->spp, c->image, (uint32_t)c->frame, c->accumMode, s);
-	ptLaunchFrameEnd(c->counters, c->maxDepth, c->dStats, s);
+	ptLaunchFrameEnd(c->counters, c->maxDepth, c->dStats, c->cfg.waveRays, c->cfg.bounceWaves, s);
 	PT_HIP(c, hipGetLastError());
 	c->framesRendered++;
 	return PT_OK;

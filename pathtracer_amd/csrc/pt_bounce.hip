@@ -24,6 +24,8 @@ constexpr int kStackLds = 12;  // traversal stack entries per lane held in LDS; 
 constexpr int kInFields = 13;  // ox oy oz ix iy iz Sx Sy Sz kpack(kz | sign bits) seed id rayIdx
 constexpr int kDoneFields = 7; // V W det prim seed id rayIdx
 constexpr int kDoneRing = 128;
+constexpr uint32_t kUnit = 64;   // records per work claim unit (= one staging batch)
+constexpr uint32_t kUnitsPerChunk = PT_CHUNK / kUnit;
 
 __device__ __forceinline__ uint32_t popc64(unsigned long long m) { return (uint32_t)__popcll(m); }
 
@@ -32,7 +34,7 @@ __global__ void __launch_bounds__(PT_WAVE)
     k_bounce(PtSceneDev sc, const float4 *__restrict__ rayOIn, const float4 *__restrict__ rayDIn,
              const float4 *__restrict__ thrIn, float4 *__restrict__ rayOOut, float4 *__restrict__ rayDOut,
              float4 *__restrict__ thrOut, const uint32_t *__restrict__ chunkCountIn, uint32_t *__restrict__ chunkCountOut,
-             const uint32_t *numChunksInPtr, uint32_t *chunkHead, uint32_t *numChunksOut, uint32_t *raysOut,
+             const uint32_t *numChunksInPtr, uint32_t *chunkHead, uint32_t *numChunksOut, uint32_t *waveRays,
              uint32_t denseN, float4 *__restrict__ rad, float tmin, float tmax, int lastBounce, uint32_t *spill,
              uint32_t spillStride, unsigned long long *trav)
 {
@@ -46,7 +48,14 @@ __global__ void __launch_bounds__(PT_WAVE)
 	uint32_t *mySpill = spill + (size_t)blockIdx.x * PT_WAVE + lane;
 
 	// wave-uniform cursors
-	uint32_t chunkBase = 0, chunkPos = 0, chunkCnt = 0;  // input chunk being consumed
+	uint32_t chunkBase = 0, chunkPos = 0, chunkCnt = 0;  // input unit being consumed (a quarter of a chunk)
+	const uint32_t totalUnits = numChunksIn * kUnitsPerChunk;
+	uint32_t unitCur = 0, unitEnd = 0;                   // claimed units [unitCur, unitEnd)
+	const uint32_t firstShare = totalUnits / (2u * gridDim.x);
+	const uint32_t firstK = firstShare >= kUnitsPerChunk ? kUnitsPerChunk : (firstShare == 0 ? 1u : firstShare);
+	const uint32_t headBias = gridDim.x * firstK;        // units handed out statically
+	bool firstClaim = true;
+	uint32_t lastSeen = headBias;
 	bool exhausted = (numChunksIn == 0);
 	uint32_t inCount = 0, inPos = 0;                     // prepared rays in sIn
 	uint32_t doneHead = 0, doneTail = 0;                 // ring of finished rays
@@ -140,25 +149,65 @@ __global__ void __launch_bounds__(PT_WAVE)
 				if (exhausted) break;
 				if (chunkPos == chunkCnt)
 				{
-					uint32_t c = 0;
-					if (lane == 0) c = atomicAdd(chunkHead, 1u);
-					c = __builtin_amdgcn_readfirstlane(c);
-					if (c >= numChunksIn)
+					// Work is claimed in units of 64 records (one staging batch; 16 per chunk) with guided
+					// self-scheduling: up to 16 units per atomic while plenty of work is left (a single counter
+					// sustains ~88 claims/us), fewer near the end so the last waves finish within a batch of
+					// each other.  The first claim of every wave is static (no atomic: the counter is read as
+					// if it started at gridDim * firstK), and a wave that can see the queue is exhausted
+					// leaves without touching the counter.
+					if (unitCur == unitEnd)
 					{
-						exhausted = true;
-						break;
+						uint32_t c, k;
+						if (firstClaim)
+						{
+							firstClaim = false;
+							k = firstK;
+							c = blockIdx.x * firstK;
+						}
+						else
+						{
+							const uint32_t seen = lastSeen;  // counter value at this wave's previous claim
+							if (seen >= totalUnits)
+							{
+								exhausted = true;
+								break;
+							}
+							// guided: half of an even share of what is left, clamped to [4, 16] units: >= 256 records
+							// per atomic keeps 4096 waves below the counter's throughput, <= 1024 bounds the tail
+							const uint32_t share = (totalUnits - seen) / (2u * gridDim.x);
+							k = share >= kUnitsPerChunk ? kUnitsPerChunk : (share <= 4u ? 4u : share);
+							c = 0;
+							if (lane == 0) c = atomicAdd(chunkHead, k);
+							c = __builtin_amdgcn_readfirstlane(c) + headBias;
+						}
+						if (c >= totalUnits)
+						{
+							exhausted = true;
+							break;
+						}
+						lastSeen = c + k;
+						unitCur = c;
+						unitEnd = c + k < totalUnits ? c + k : totalUnits;
 					}
+					const uint32_t u = unitCur++;
+					const uint32_t chunk = u / kUnitsPerChunk, lo = (u % kUnitsPerChunk) * kUnit;
 					uint32_t cnt;
 					if (denseN)
 					{
-						uint32_t rem = denseN - c * PT_CHUNK;
+						uint32_t rem = denseN - chunk * PT_CHUNK;
 						cnt = rem < PT_CHUNK ? rem : PT_CHUNK;
 					}
-					else cnt = __builtin_amdgcn_readfirstlane(chunkCountIn[c]);
-					chunkBase = c * PT_CHUNK;
+					else cnt = __builtin_amdgcn_readfirstlane(chunkCountIn[chunk]);
+					if (lo >= cnt)
+					{
+						// the rest of this chunk holds no records: skip to the next chunk boundary
+						uint32_t nextChunkUnit = (chunk + 1) * kUnitsPerChunk;
+						unitCur = nextChunkUnit < unitEnd ? nextChunkUnit : unitEnd;
+						continue;
+					}
+					chunkBase = chunk * PT_CHUNK + lo;
 					chunkPos = 0;
-					chunkCnt = cnt;
-					if (cnt == 0) continue;
+					chunkCnt = (cnt - lo < kUnit) ? cnt - lo : kUnit;
 				}
 				// prepare the next (up to) 64 rays of the chunk at full utilisation
 				uint32_t n = chunkCnt - chunkPos;
@@ -428,7 +477,7 @@ __global__ void __launch_bounds__(PT_WAVE)
 	if (lane == 0)
 	{
 		if (outChunk != 0xFFFFFFFFu) chunkCountOut[outChunk] = outPos;
-		if (raysFetched) atomicAdd(raysOut, raysFetched);
+		if (raysFetched) waveRays[blockIdx.x] += raysFetched;  // one wave per slot per launch: no atomic needed
 	}
 	if (kStats)
 	{
@@ -458,7 +507,7 @@ void ptLaunchBounce(const PtSceneDev &sc, const PtQueues &q, int in, PtFrameCoun
 #define PT_BOUNCE(S)                                                                                                   \
 	k_bounce<S><<<cfg.bounceWaves, PT_WAVE, 0, s>>>(sc, q.rayO[in], q.rayD[in], q.thr[in], q.rayO[out], q.rayD[out],   \
 	                                                q.thr[out], q.chunkCount[in], q.chunkCount[out], &fc->numChunks[depth], \
-	                                                &fc->chunkHead[depth], &fc->numChunks[depth + 1], &fc->count[depth], \
+	                                                &fc->chunkHead[depth], &fc->numChunks[depth + 1], cfg.waveRays, \
 	                                                denseN, q.rad, tmin, tmax, lastBounce, cfg.spill, cfg.spillStride,   \
 	                                                travStats)
 	if (travStats) PT_BOUNCE(true);

@@ -33,10 +33,12 @@ struct PtLaunchCfg
 	uint32_t *spill;            // persistentBlocks*256*PT_SPILL_STACK words
 	uint32_t spillStride;       // lanes the spill strip is laid out for
 	uint32_t bounceWaves;       // grid of the fused k_bounce kernel (single-wave blocks)
+	uint32_t *waveRays;         // bounceWaves counters: rays fetched by each wave slot during the frame
 };
 
 void ptLaunchFrameBegin(PtFrameCounters *fc, uint32_t nPaths, int fused, hipStream_t s);
-void ptLaunchFrameEnd(const PtFrameCounters *fc, int depth, unsigned long long *stats, hipStream_t s);
+void ptLaunchFrameEnd(const PtFrameCounters *fc, int depth, unsigned long long *stats, uint32_t *waveRays,
+                      uint32_t nWaveRays, hipStream_t s);
 void ptLaunchGenerate(const PtCamera &cam, uint32_t W, uint32_t H, uint32_t spp, uint32_t seedWord, int centreJitter,
                       const PtQueues &q, hipStream_t s);
 void ptLaunchExtend(const PtSceneDev &sc, bool brute, const uint32_t *count, uint32_t *head, const float4 *rayO,

@@ -358,14 +358,26 @@ __global__ void k_frame_begin(PtFrameCounters *fc, uint32_t nPaths, int fused)
 	}
 }
 
-__global__ void k_frame_end(const PtFrameCounters *fc, int depth, unsigned long long *stats)
+__global__ void k_frame_end(const PtFrameCounters *fc, int depth, unsigned long long *stats, uint32_t *waveRays,
+                            uint32_t nWaveRays)
 {
+	// split pipeline: rays = sum of the queue lengths; fused pipeline: sum of the per-wave fetch counters
+	__shared__ unsigned long long part[256];
+	unsigned long long r = 0;
+	for (uint32_t i = threadIdx.x; i < nWaveRays; i += blockDim.x)
+	{
+		r += waveRays[i];
+		waveRays[i] = 0;
+	}
+	part[threadIdx.x] = r;
+	__syncthreads();
 	if (threadIdx.x == 0)
 	{
-		unsigned long long r = 0;
-		for (int d = 0; d < depth; ++d) r += fc->count[d];
-		stats[0] += r;  // rays_total
-		stats[1] = r;   // rays_last_frame
+		unsigned long long total = 0;
+		for (int i = 0; i < 256; ++i) total += part[i];
+		for (int d = 0; d < depth; ++d) total += fc->count[d];
+		stats[0] += total;  // rays_total
+		stats[1] = total;   // rays_last_frame
 	}
 }
 
@@ -425,9 +437,10 @@ void ptLaunchFrameBegin(PtFrameCounters *fc, uint32_t nPaths, int fused, hipStre
 	k_frame_begin<<<1, 256, 0, s>>>(fc, nPaths, fused);
 }
 
-void ptLaunchFrameEnd(const PtFrameCounters *fc, int depth, unsigned long long *stats, hipStream_t s)
+void ptLaunchFrameEnd(const PtFrameCounters *fc, int depth, unsigned long long *stats, uint32_t *waveRays,
+                      uint32_t nWaveRays, hipStream_t s)
 {
-	k_frame_end<<<1, 64, 0, s>>>(fc, depth, stats);
+	k_frame_end<<<1, 256, 0, s>>>(fc, depth, stats, waveRays, nWaveRays);
 }
 
 void ptLaunchGenerate(const PtCamera &cam, uint32_t W, uint32_t H, uint32_t spp, uint32_t seedWord, int centreJitter,
