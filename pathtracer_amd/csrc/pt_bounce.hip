@@ -18,12 +18,17 @@
 // images stay bit-identical to the split pipeline and to the CPU oracle.
 #include "pt_trace.h"
 
+#ifndef PT_REFILL_LANES
+#define PT_REFILL_LANES 8
+#endif
+
 namespace
 {
 constexpr int kStackLds = 12;  // traversal stack entries per lane held in LDS; deeper ones spill to global
 constexpr int kInFields = 13;  // ox oy oz ix iy iz Sx Sy Sz kpack(kz | sign bits) seed id rayIdx
 constexpr int kDoneFields = 7; // V W det prim seed id rayIdx
 constexpr int kDoneRing = 128;
+constexpr uint32_t kRefillLanes = PT_REFILL_LANES;  // finished lanes that trigger a retire + refill pass
 constexpr uint32_t kUnit = 64;   // records per work claim unit (= one staging batch)
 constexpr uint32_t kUnitsPerChunk = PT_CHUNK / kUnit;
 
@@ -140,167 +145,202 @@ __global__ void __launch_bounds__(PT_WAVE)
 
 	for (;;)
 	{
-		// ------------------------------------------------------------------ A: refill idle lanes ----
-		unsigned long long idle = __ballot(cur == PT_TRAVERSAL_DONE);
-		while (idle)
+		// Retire + refill only when enough lanes wait for it (or nothing else is left to do): the section
+		// costs about half a node step, so it is not run for every single finished lane.
+		const uint32_t nIdle = popc64(__ballot(cur == PT_TRAVERSAL_DONE));
+		if (nIdle >= kRefillLanes)
 		{
-			if (inPos == inCount)
+			// ------------------------------------------------------------------ C: retire finished lanes ----
+			bool fin = (rayIdx != 0xFFFFFFFFu) && (cur == PT_TRAVERSAL_DONE);
+			unsigned long long fm = __ballot(fin);
+			if (fm)
 			{
-				if (exhausted) break;
-				if (chunkPos == chunkCnt)
+				if (fin)
 				{
-					// Work is claimed in units of 64 records (one staging batch; 16 per chunk) with guided
-					// self-scheduling: up to 16 units per atomic while plenty of work is left (a single counter
-					// sustains ~88 claims/us), fewer near the end so the last waves finish within a batch of
-					// each other.  The first claim of every wave is static (no atomic: the counter is read as
-					// if it started at gridDim * firstK), and a wave that can see the queue is exhausted
-					// leaves without touching the counter.
-					if (unitCur == unitEnd)
+					uint32_t e = (doneTail + popc64(fm & lanesBelow)) & (kDoneRing - 1);
+					sDone[0][e] = __float_as_uint(best.V);
+					sDone[1][e] = __float_as_uint(best.W);
+					sDone[2][e] = __float_as_uint(best.det);
+					sDone[3][e] = best.prim;
+					sDone[4][e] = seed;
+					sDone[5][e] = id;
+					sDone[6][e] = rayIdx;
+					rayIdx = 0xFFFFFFFFu;
+				}
+				doneTail += popc64(fm);
+				if (doneTail - doneHead >= PT_WAVE)
+				{
+					__syncthreads();
+					flush(PT_WAVE);
+					__syncthreads();
+				}
+			}
+			// ------------------------------------------------------------------ A: refill idle lanes ----
+			unsigned long long idle = __ballot(cur == PT_TRAVERSAL_DONE);
+			while (idle)
+			{
+				if (inPos == inCount)
+				{
+					if (exhausted) break;
+					if (chunkPos == chunkCnt)
 					{
-						uint32_t c, k;
-						if (firstClaim)
+						// Work is claimed in units of 64 records (one staging batch; 16 per chunk) with guided
+						// self-scheduling: up to 16 units per atomic while plenty of work is left (a single counter
+						// sustains ~88 claims/us), fewer near the end so the last waves finish within a batch of
+						// each other.  The first claim of every wave is static (no atomic: the counter is read as
+						// if it started at gridDim * firstK), and a wave that can see the queue is exhausted
+						// leaves without touching the counter.
+						if (unitCur == unitEnd)
 						{
-							firstClaim = false;
-							k = firstK;
-							c = blockIdx.x * firstK;
-						}
-						else
-						{
-							const uint32_t seen = lastSeen;  // counter value at this wave's previous claim
-							if (seen >= totalUnits)
+							uint32_t c, k;
+							if (firstClaim)
+							{
+								firstClaim = false;
+								k = firstK;
+								c = blockIdx.x * firstK;
+							}
+							else
+							{
+								const uint32_t seen = lastSeen;  // counter value at this wave's previous claim
+								if (seen >= totalUnits)
+								{
+									exhausted = true;
+									break;
+								}
+								// guided: half of an even share of what is left, clamped to [4, 16] units: >= 256 records
+								// per atomic keeps 4096 waves below the counter's throughput, <= 1024 bounds the tail
+								const uint32_t share = (totalUnits - seen) / (2u * gridDim.x);
+								k = share >= kUnitsPerChunk ? kUnitsPerChunk : (share <= 4u ? 4u : share);
+								c = 0;
+								if (lane == 0) c = atomicAdd(chunkHead, k);
+								c = __builtin_amdgcn_readfirstlane(c) + headBias;
+							}
+							if (c >= totalUnits)
 							{
 								exhausted = true;
 								break;
 							}
-							// guided: half of an even share of what is left, clamped to [4, 16] units: >= 256 records
-							// per atomic keeps 4096 waves below the counter's throughput, <= 1024 bounds the tail
-							const uint32_t share = (totalUnits - seen) / (2u * gridDim.x);
-							k = share >= kUnitsPerChunk ? kUnitsPerChunk : (share <= 4u ? 4u : share);
-							c = 0;
-							if (lane == 0) c = atomicAdd(chunkHead, k);
-							c = __builtin_amdgcn_readfirstlane(c) + headBias;
+							lastSeen = c + k;
+							unitCur = c;
+							unitEnd = c + k < totalUnits ? c + k : totalUnits;
 						}
-						if (c >= totalUnits)
+						const uint32_t u = unitCur++;
+						const uint32_t chunk = u / kUnitsPerChunk, lo = (u % kUnitsPerChunk) * kUnit;
+						uint32_t cnt;
+						if (denseN)
 						{
-							exhausted = true;
-							break;
+							uint32_t rem = denseN - chunk * PT_CHUNK;
+							cnt = rem < PT_CHUNK ? rem : PT_CHUNK;
 						}
-						lastSeen = c + k;
-						unitCur = c;
-						unitEnd = c + k < totalUnits ? c + k : totalUnits;
+						else cnt = __builtin_amdgcn_readfirstlane(chunkCountIn[chunk]);
+						if (lo >= cnt)
+						{
+							// the rest of this chunk holds no records: skip to the next chunk boundary
+							uint32_t nextChunkUnit = (chunk + 1) * kUnitsPerChunk;
+							unitCur = nextChunkUnit < unitEnd ? nextChunkUnit : unitEnd;
+							continue;
+						}
+						chunkBase = chunk * PT_CHUNK + lo;
+						chunkPos = 0;
+						chunkCnt = (cnt - lo < kUnit) ? cnt - lo : kUnit;
 					}
-					const uint32_t u = unitCur++;
-					const uint32_t chunk = u / kUnitsPerChunk, lo = (u % kUnitsPerChunk) * kUnit;
-					uint32_t cnt;
-					if (denseN)
+					// prepare the next (up to) 64 rays of the chunk at full utilisation
+					uint32_t n = chunkCnt - chunkPos;
+					if (n > PT_WAVE) n = PT_WAVE;
+					__syncthreads();  // all lanes are done reading the previous staging contents
+					if ((uint32_t)lane < n)
 					{
-						uint32_t rem = denseN - chunk * PT_CHUNK;
-						cnt = rem < PT_CHUNK ? rem : PT_CHUNK;
+						uint32_t ridx = chunkBase + chunkPos + lane;
+						float4 ro = rayOIn[ridx], rd = rayDIn[ridx];
+						float3x d = { rd.x, rd.y, rd.z };
+						// dominant axis kz; the other two follow cyclically (kx = kz+1, ky = kz+2 mod 3).  Woop's
+						// winding swap for d[kz] < 0 is omitted: it negates U, V, W, det and T exactly and leaves
+						// t, u, v unchanged, so results equal the oracle's (which keeps the swap) bit for bit.
+						float ad0 = fabsf(d.x), ad1 = fabsf(d.y), ad2 = fabsf(d.z);
+						uint32_t kz = 0;
+						float am = ad0;
+						if (ad1 > am)
+						{
+							kz = 1;
+							am = ad1;
+						}
+						if (ad2 > am) kz = 2;
+						float dkz = kz == 0 ? d.x : (kz == 1 ? d.y : d.z);
+						float dkx = kz == 0 ? d.y : (kz == 1 ? d.z : d.x);
+						float dky = kz == 0 ? d.z : (kz == 1 ? d.x : d.y);
+						PtRayShear rs;
+						rs.Sx = dkx / dkz;
+						rs.Sy = dky / dkz;
+						rs.Sz = 1.0f / dkz;
+						// box test only: zero components nudged so that 0 * inf cannot occur (interval stays huge)
+						float dcx = fabsf(d.x) > 1e-30f ? d.x : copysignf(1e-30f, d.x);
+						float dcy = fabsf(d.y) > 1e-30f ? d.y : copysignf(1e-30f, d.y);
+						float dcz = fabsf(d.z) > 1e-30f ? d.z : copysignf(1e-30f, d.z);
+						float rx = 1.0f / dcx, ry = 1.0f / dcy, rz = 1.0f / dcz;
+						uint32_t kp = kz | ((rx < 0.0f) ? 64u : 0u) | ((ry < 0.0f) ? 128u : 0u) | ((rz < 0.0f) ? 256u : 0u);
+						sIn[0][lane] = __float_as_uint(ro.x);
+						sIn[1][lane] = __float_as_uint(ro.y);
+						sIn[2][lane] = __float_as_uint(ro.z);
+						sIn[3][lane] = __float_as_uint(rx);
+						sIn[4][lane] = __float_as_uint(ry);
+						sIn[5][lane] = __float_as_uint(rz);
+						sIn[6][lane] = __float_as_uint(rs.Sx);
+						sIn[7][lane] = __float_as_uint(rs.Sy);
+						sIn[8][lane] = __float_as_uint(rs.Sz);
+						sIn[9][lane] = kp;
+						sIn[10][lane] = __float_as_uint(ro.w);
+						sIn[11][lane] = __float_as_uint(rd.w);
+						sIn[12][lane] = ridx;
 					}
-					else cnt = __builtin_amdgcn_readfirstlane(chunkCountIn[chunk]);
-					if (lo >= cnt)
-					{
-						// the rest of this chunk holds no records: skip to the next chunk boundary
-						uint32_t nextChunkUnit = (chunk + 1) * kUnitsPerChunk;
-						unitCur = nextChunkUnit < unitEnd ? nextChunkUnit : unitEnd;
-						continue;
-					}
-					chunkBase = chunk * PT_CHUNK + lo;
-					chunkPos = 0;
-					chunkCnt = (cnt - lo < kUnit) ? cnt - lo : kUnit;
+					__syncthreads();
+					chunkPos += n;
+					inCount = n;
+					inPos = 0;
+					raysFetched += n;
 				}
-				// prepare the next (up to) 64 rays of the chunk at full utilisation
-				uint32_t n = chunkCnt - chunkPos;
-				if (n > PT_WAVE) n = PT_WAVE;
-				__syncthreads();  // all lanes are done reading the previous staging contents
-				if ((uint32_t)lane < n)
+				uint32_t avail = inCount - inPos, want = popc64(idle);
+				uint32_t n = want < avail ? want : avail;
+				uint32_t rank = popc64(idle & lanesBelow);
+				bool take = (idle & laneBit) && rank < n;
+				if (take)
 				{
-					uint32_t ridx = chunkBase + chunkPos + lane;
-					float4 ro = rayOIn[ridx], rd = rayDIn[ridx];
-					float3x d = { rd.x, rd.y, rd.z };
-					// dominant axis kz; the other two follow cyclically (kx = kz+1, ky = kz+2 mod 3).  Woop's
-					// winding swap for d[kz] < 0 is omitted: it negates U, V, W, det and T exactly and leaves
-					// t, u, v unchanged, so results equal the oracle's (which keeps the swap) bit for bit.
-					float ad0 = fabsf(d.x), ad1 = fabsf(d.y), ad2 = fabsf(d.z);
-					uint32_t kz = 0;
-					float am = ad0;
-					if (ad1 > am)
-					{
-						kz = 1;
-						am = ad1;
-					}
-					if (ad2 > am) kz = 2;
-					float dkz = kz == 0 ? d.x : (kz == 1 ? d.y : d.z);
-					float dkx = kz == 0 ? d.y : (kz == 1 ? d.z : d.x);
-					float dky = kz == 0 ? d.z : (kz == 1 ? d.x : d.y);
-					PtRayShear rs;
-					rs.Sx = dkx / dkz;
-					rs.Sy = dky / dkz;
-					rs.Sz = 1.0f / dkz;
-					// box test only: zero components nudged so that 0 * inf cannot occur (interval stays huge)
-					float dcx = fabsf(d.x) > 1e-30f ? d.x : copysignf(1e-30f, d.x);
-					float dcy = fabsf(d.y) > 1e-30f ? d.y : copysignf(1e-30f, d.y);
-					float dcz = fabsf(d.z) > 1e-30f ? d.z : copysignf(1e-30f, d.z);
-					float rx = 1.0f / dcx, ry = 1.0f / dcy, rz = 1.0f / dcz;
-					uint32_t kp = kz | ((rx < 0.0f) ? 64u : 0u) | ((ry < 0.0f) ? 128u : 0u) | ((rz < 0.0f) ? 256u : 0u);
-					sIn[0][lane] = __float_as_uint(ro.x);
-					sIn[1][lane] = __float_as_uint(ro.y);
-					sIn[2][lane] = __float_as_uint(ro.z);
-					sIn[3][lane] = __float_as_uint(rx);
-					sIn[4][lane] = __float_as_uint(ry);
-					sIn[5][lane] = __float_as_uint(rz);
-					sIn[6][lane] = __float_as_uint(rs.Sx);
-					sIn[7][lane] = __float_as_uint(rs.Sy);
-					sIn[8][lane] = __float_as_uint(rs.Sz);
-					sIn[9][lane] = kp;
-					sIn[10][lane] = __float_as_uint(ro.w);
-					sIn[11][lane] = __float_as_uint(rd.w);
-					sIn[12][lane] = ridx;
+					uint32_t s = inPos + rank;
+					ox = __uint_as_float(sIn[0][s]);
+					oy = __uint_as_float(sIn[1][s]);
+					oz = __uint_as_float(sIn[2][s]);
+					ix = __uint_as_float(sIn[3][s]);
+					iy = __uint_as_float(sIn[4][s]);
+					iz = __uint_as_float(sIn[5][s]);
+					Sx = __uint_as_float(sIn[6][s]);
+					Sy = __uint_as_float(sIn[7][s]);
+					Sz = __uint_as_float(sIn[8][s]);
+					kpack = sIn[9][s];
+					seed = sIn[10][s];
+					id = sIn[11][s];
+					rayIdx = sIn[12][s];
+					best.t = tmax;
+					best.prim = PT_NO_HIT;
+					best.V = 0.0f;
+					best.W = 0.0f;
+					best.det = 1.0f;
+					sStack[0][lane] = PT_TRAVERSAL_DONE;  // sentinel: popping an empty stack ends the traversal
+					sp = 1;
+					cur = sc.nNodes ? 0u : PT_TRAVERSAL_DONE;
 				}
-				__syncthreads();
-				chunkPos += n;
-				inCount = n;
-				inPos = 0;
-				raysFetched += n;
+				inPos += n;
+				idle &= ~__ballot(take);
 			}
-			uint32_t avail = inCount - inPos, want = popc64(idle);
-			uint32_t n = want < avail ? want : avail;
-			uint32_t rank = popc64(idle & lanesBelow);
-			bool take = (idle & laneBit) && rank < n;
-			if (take)
-			{
-				uint32_t s = inPos + rank;
-				ox = __uint_as_float(sIn[0][s]);
-				oy = __uint_as_float(sIn[1][s]);
-				oz = __uint_as_float(sIn[2][s]);
-				ix = __uint_as_float(sIn[3][s]);
-				iy = __uint_as_float(sIn[4][s]);
-				iz = __uint_as_float(sIn[5][s]);
-				Sx = __uint_as_float(sIn[6][s]);
-				Sy = __uint_as_float(sIn[7][s]);
-				Sz = __uint_as_float(sIn[8][s]);
-				kpack = sIn[9][s];
-				seed = sIn[10][s];
-				id = sIn[11][s];
-				rayIdx = sIn[12][s];
-				best.t = tmax;
-				best.prim = PT_NO_HIT;
-				best.V = 0.0f;
-				best.W = 0.0f;
-				best.det = 1.0f;
-				sStack[0][lane] = PT_TRAVERSAL_DONE;  // sentinel: popping an empty stack ends the traversal
-				sp = 1;
-				cur = sc.nNodes ? 0u : PT_TRAVERSAL_DONE;
-			}
-			inPos += n;
-			idle &= ~__ballot(take);
+			if (!__ballot(rayIdx != 0xFFFFFFFFu)) break;  // input exhausted and every lane retired
 		}
-		unsigned long long hasRay = __ballot(rayIdx != 0xFFFFFFFFu);
-		if (!hasRay) break;  // input exhausted and every lane retired
 
 		// ------------------------------------------------------------------ B: traverse ----
-		// inner nodes: every lane that sits on one steps together ...
-		while (!(cur & PT_LEAF_FLAG))
+		// One step for the LARGER of the two groups -- lanes on an inner node or lanes on a leaf -- the other
+		// group waits: at least half of the busy lanes work in every step (a phase that runs until its group
+		// is empty decays towards a single lane).
+		const unsigned long long nodeLanes = __ballot(!(cur & PT_LEAF_FLAG));
+		const unsigned long long leafLanes = __ballot((cur & PT_LEAF_FLAG) && cur != PT_TRAVERSAL_DONE);
+		const bool doNode = popc64(nodeLanes) >= popc64(leafLanes);
+		if (doNode && !(cur & PT_LEAF_FLAG))
 		{
 			if (kStats) ++nodeFetches;
 			const uint4 *np = reinterpret_cast<const uint4 *>(sc.nodes + cur);
@@ -385,8 +425,7 @@ __global__ void __launch_bounds__(PT_WAVE)
 				}
 			}
 		}
-		// ... then every lane that sits on a leaf
-		while ((cur & PT_LEAF_FLAG) && cur != PT_TRAVERSAL_DONE)
+		if (!doNode && (cur & PT_LEAF_FLAG) && cur != PT_TRAVERSAL_DONE)
 		{
 			// the next entry is needed whatever the triangles say: read it first
 			--sp;
@@ -445,31 +484,6 @@ __global__ void __launch_bounds__(PT_WAVE)
 			cur = next;
 		}
 
-		// ------------------------------------------------------------------ C: retire finished lanes ----
-		bool fin = (rayIdx != 0xFFFFFFFFu) && (cur == PT_TRAVERSAL_DONE);
-		unsigned long long fm = __ballot(fin);
-		if (fm)
-		{
-			if (fin)
-			{
-				uint32_t e = (doneTail + popc64(fm & lanesBelow)) & (kDoneRing - 1);
-				sDone[0][e] = __float_as_uint(best.V);
-				sDone[1][e] = __float_as_uint(best.W);
-				sDone[2][e] = __float_as_uint(best.det);
-				sDone[3][e] = best.prim;
-				sDone[4][e] = seed;
-				sDone[5][e] = id;
-				sDone[6][e] = rayIdx;
-				rayIdx = 0xFFFFFFFFu;
-			}
-			doneTail += popc64(fm);
-			if (doneTail - doneHead >= PT_WAVE)
-			{
-				__syncthreads();
-				flush(PT_WAVE);
-				__syncthreads();
-			}
-		}
 	}
 	// drain the ring
 	__syncthreads();
