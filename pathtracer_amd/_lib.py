@@ -8,7 +8,8 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libpt_hip.so")
+# PT_HIP_LIB selects an alternative build of the same library (kernel tuning experiments)
+LIB_PATH = os.environ.get("PT_HIP_LIB") or os.path.join(_HERE, "libpt_hip.so")
 
 PT_OK = 0
 PT_NO_HIT = 0xFFFFFFFF

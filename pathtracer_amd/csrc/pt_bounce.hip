@@ -18,8 +18,12 @@
 // images stay bit-identical to the split pipeline and to the CPU oracle.
 #include "pt_trace.h"
 
+#ifndef PT_NODE_WEIGHT
+#define PT_NODE_WEIGHT 1u
+#define PT_LEAF_WEIGHT 1u
+#endif
 #ifndef PT_REFILL_LANES
-#define PT_REFILL_LANES 8
+#define PT_REFILL_LANES 16
 #endif
 
 namespace
@@ -339,7 +343,7 @@ __global__ void __launch_bounds__(PT_WAVE)
 		// is empty decays towards a single lane).
 		const unsigned long long nodeLanes = __ballot(!(cur & PT_LEAF_FLAG));
 		const unsigned long long leafLanes = __ballot((cur & PT_LEAF_FLAG) && cur != PT_TRAVERSAL_DONE);
-		const bool doNode = popc64(nodeLanes) >= popc64(leafLanes);
+		const bool doNode = popc64(nodeLanes) * PT_NODE_WEIGHT >= popc64(leafLanes) * PT_LEAF_WEIGHT;
 		if (doNode && !(cur & PT_LEAF_FLAG))
 		{
 			if (kStats) ++nodeFetches;
