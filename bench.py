@@ -46,6 +46,7 @@ def parse():
     ap.add_argument("--cpu-sample-frames", type=int, default=1)
     ap.add_argument("--out-image", default="")
     ap.add_argument("--pipeline", choices=["fused", "split"], default="fused")
+    ap.add_argument("--force-dist", action="store_true", help="initialise torch.distributed/RCCL even for one rank (rehearses the N>1 path on one GPU)")
     return ap.parse_args()
 
 
@@ -65,10 +66,10 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     dist = None
     torch = None
-    if n_gpus > 1:
+    if n_gpus > 1 or a.force_dist:
         import torch
         import torch.distributed as dist
-        if world != n_gpus:
+        if world != n_gpus and not a.force_dist:
             raise SystemExit(f"--gpus {n_gpus} needs WORLD_SIZE={n_gpus} (launch with torch.distributed.run); got {world}")
         torch.cuda.set_device(local_rank)
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
@@ -89,7 +90,7 @@ def main():
     rt.setParams(spp_per_frame=S, max_depth=D, tmin=1e-3, tmax=1e4, seed=0, max_frames=0)
     first, stride = multigpu.frame_schedule(rank, world)
     rt.setFrameSchedule(first=first, stride=stride)
-    rt.setAccumMode(PT_ACCUM_SUM if world > 1 else PT_ACCUM_MEAN)
+    rt.setAccumMode(PT_ACCUM_SUM if dist is not None else PT_ACCUM_MEAN)
     rt.setPipeline(PT_PIPELINE_FUSED if a.pipeline == "fused" else PT_PIPELINE_SPLIT)
 
     def barrier():
@@ -150,7 +151,7 @@ def main():
 
     if a.out_image and rank == 0:
         img = rt.readImage()
-        if world > 1:
+        if dist is not None:
             multigpu.finalize_mean(img, world * a.steps)
         np.save(a.out_image, img)
 
