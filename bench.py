@@ -46,6 +46,7 @@ def parse():
     ap.add_argument("--cpu-sample-frames", type=int, default=1)
     ap.add_argument("--out-image", default="")
     ap.add_argument("--pipeline", choices=["fused", "split"], default="fused")
+    ap.add_argument("--builder", choices=["ploc", "lbvh"], default="ploc", help="BVH2 construction before the BVH4 collapse")
     ap.add_argument("--force-dist", action="store_true", help="initialise torch.distributed/RCCL even for one rank (rehearses the N>1 path on one GPU)")
     return ap.parse_args()
 
@@ -83,7 +84,7 @@ def main():
     scene = pa.scenes.cornell_box()
     view, proj = pa.reference_camera(W, H)
     rt = pa.HipRaytracing(local_rank)
-    rt.buildBlas(scene)
+    rt.buildBlas(scene, pa.api.PT_ACCEL_BVH4_PLOC if a.builder == "ploc" else pa.api.PT_ACCEL_BVH4)
     rt.buildTlas()
     rt.resize(W, H)
     rt.setCamera(view, proj)
@@ -190,7 +191,7 @@ def main():
             "warmup": a.warmup, "ms_per_step": round(dt_max / a.steps * 1e3, 4), "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": f"Cornell box {W}x{H}, {S} spp/frame x {a.steps} frames/GPU, max depth {D}, "
-                                   "wavefront path tracer, quantised BVH4 (BASELINE.json configs[1])",
+                                   f"wavefront path tracer, quantised BVH4 ({a.builder.upper()}) (BASELINE.json configs[1])",
                        "width": W, "height": H, "spp_per_frame": S, "max_depth": D,
                        "total_spp": total_spp, "parallelism": f"sample-stream x{world}"},
             "samples_per_px_per_s": round(total_spp / dt_max, 3),
@@ -212,7 +213,7 @@ def main():
                               "queue_only_frac": round(mrays / world * 1e6 * 160.0 / 1e9 / HBM_PEAK_GBS, 5)},
             "kernel_ms": {("bounce_mean" if a.pipeline == "fused" else "extend_mean"): round(ext_ms, 4),
                           "shade_mean": round(st.shade_ms_total / max(1, st.shade_launches), 4)},
-            "pipeline": a.pipeline,
+            "pipeline": a.pipeline, "builder": a.builder,
             "bvh": {"nodes": st.bvh_nodes, "depth": st.bvh_depth, "tris": st.bvh_tris, "build_ms": round(st.build_ms, 3)},
         }
         if world == 1 and not a.no_cpu_baseline:

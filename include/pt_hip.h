@@ -109,6 +109,7 @@ int pt_upload_scene(pt_ctx *ctx, const PtVertex *vertices, uint32_t n_vertices, 
 
 #define PT_ACCEL_BVH4 0         /* LBVH (Morton + LDS radix sort) collapsed to a quantised BVH4 */
 #define PT_ACCEL_BRUTE_FORCE 1  /* no hierarchy: every ray tests every triangle (parity/debug mode) */
+#define PT_ACCEL_BVH4_PLOC 2    /* same sort, BVH2 by parallel locally-ordered clustering (radius 16), same BVH4 */
 #define PT_ACCEL_LEAF_SIZE(n) ((n) << 8) /* OR into flags: at most n (1..8) triangles per leaf; 0 = default */
 
 /* VulkanRaytracing::buildBlas + buildTlas (VulkanRaytracing.cpp:147-262,448-527): what the

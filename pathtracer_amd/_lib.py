@@ -15,6 +15,7 @@ PT_OK = 0
 PT_NO_HIT = 0xFFFFFFFF
 PT_ACCEL_BVH4 = 0
 PT_ACCEL_BRUTE_FORCE = 1
+PT_ACCEL_BVH4_PLOC = 2
 PT_ACCUM_MEAN = 0
 PT_ACCUM_SUM = 1
 PT_PROFILE_KERNELS = 1

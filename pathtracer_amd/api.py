@@ -14,7 +14,7 @@ from dataclasses import dataclass
 import numpy as np
 
 from . import _lib
-from ._lib import (PT_ACCEL_BRUTE_FORCE, PT_ACCEL_BVH4, PT_ACCUM_MEAN, PT_ACCUM_SUM, PT_NO_HIT, PT_PROFILE_KERNELS,
+from ._lib import (PT_ACCEL_BRUTE_FORCE, PT_ACCEL_BVH4, PT_ACCEL_BVH4_PLOC, PT_ACCUM_MEAN, PT_ACCUM_SUM, PT_NO_HIT, PT_PROFILE_KERNELS,
                    PT_PROFILE_TRAVERSAL, PT_PIPELINE_FUSED, PT_PIPELINE_SPLIT, PtStats)
 
 HIT_DTYPE = np.dtype([("t", np.float32), ("u", np.float32), ("v", np.float32), ("prim", np.uint32)])
@@ -157,7 +157,7 @@ class HipRaytracing:
                                             s.indices.size, _p(s.materials), s.materials.shape[0], _p(s.mat_indices)))
         self._scene = s
 
-    def buildBlas(self, scene: Scene | None = None, flags: int = PT_ACCEL_BVH4):
+    def buildBlas(self, scene: Scene | None = None, flags: int = PT_ACCEL_BVH4_PLOC):
         """VulkanRaytracing::buildBlas (VulkanRaytracing.cpp:147-262): here the BVH is built by our own
         kernels instead of the driver.  Includes buildTlas (single identity instance)."""
         if scene is not None:
@@ -278,5 +278,5 @@ class HipRaytracing:
 
 
 __all__ = ["HipRaytracing", "PathTracerError", "Scene", "load_obj", "look_at", "perspective", "inverse4",
-           "reference_camera", "HIT_DTYPE", "NODE_DTYPE", "TRI_DTYPE", "PT_ACCEL_BVH4", "PT_ACCEL_BRUTE_FORCE",
+           "reference_camera", "HIT_DTYPE", "NODE_DTYPE", "TRI_DTYPE", "PT_ACCEL_BVH4", "PT_ACCEL_BVH4_PLOC", "PT_ACCEL_BRUTE_FORCE",
            "PT_ACCUM_MEAN", "PT_ACCUM_SUM", "PT_NO_HIT", "PT_PROFILE_KERNELS", "PT_PROFILE_TRAVERSAL", "PT_PIPELINE_FUSED", "PT_PIPELINE_SPLIT", "PtStats"]

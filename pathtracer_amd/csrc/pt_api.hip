@@ -371,7 +371,7 @@ extern "C" int pt_build_accel(pt_ctx *c, int flags)
 	if (!c) return fail(nullptr, PT_EINVAL, "null context");
 	if (!c->haveScene) return fail(c, PT_EINVAL, "pt_build_accel: no scene uploaded");
 	const int mode = flags & 0xFF, leafMax = (flags >> 8) & 0xF;
-	if ((mode != PT_ACCEL_BVH4 && mode != PT_ACCEL_BRUTE_FORCE) || (flags & ~0xFFF) || leafMax > 8)
+	if ((mode != PT_ACCEL_BVH4 && mode != PT_ACCEL_BRUTE_FORCE && mode != PT_ACCEL_BVH4_PLOC) || (flags & ~0xFFF) || leafMax > 8)
 		return fail(c, PT_EINVAL, "pt_build_accel: bad flags 0x%x", flags);
 	PT_HIP(c, hipSetDevice(c->device));
 	PT_HIP(c, hipStreamSynchronize(c->stream));
@@ -379,7 +379,8 @@ extern "C" int pt_build_accel(pt_ctx *c, int flags)
 	c->brute = (mode == PT_ACCEL_BRUTE_FORCE);
 	// The Morton codes / sorted order / BVH are built in both modes (the debug entry points read
 	// them); brute-force mode just does not traverse the hierarchy.
-	PtBuildInput in = { c->dVerts, c->dIndices, c->nIdx / 3, leafMax };
+	PtBuildInput in = { c->dVerts, c->dIndices, c->nIdx / 3, leafMax,
+	                    mode == PT_ACCEL_BVH4_PLOC ? PT_BUILDER_PLOC : PT_BUILDER_LBVH };
 	hipEvent_t a = getEvent(c), b = getEvent(c);
 	hipEventRecord(a, c->stream);
 	hipError_t e = ptBuildBvh4(in, c->accel, c->stream);

@@ -2,12 +2,15 @@
 #pragma once
 #include "pt_device_common.h"
 
+enum { PT_BUILDER_LBVH = 0, PT_BUILDER_PLOC = 1 };
+
 struct PtBuildInput
 {
 	const PtVertex *vertices;  // device
 	const uint32_t *indices;   // device
 	uint32_t nTris;
 	int leafMax;  // triangles per leaf (1..PT_LEAF_MAX); 0 = PT_LEAF_DEFAULT
+	int builder;  // PT_BUILDER_LBVH (Karras topology + refit) or PT_BUILDER_PLOC (locally-ordered clustering)
 };
 
 struct PtBuildOutput

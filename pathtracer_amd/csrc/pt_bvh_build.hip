@@ -364,20 +364,6 @@ struct CollapseTask
 	uint32_t out; // wide-node slot to write
 };
 
-__device__ __forceinline__ void nodeRange(int node, int n, const int2 *range, int &first, int &last)
-{
-	if (node >= n - 1)
-	{
-		first = last = node - (n - 1);
-	}
-	else
-	{
-		int2 r = range[node];
-		first = r.x;
-		last = r.y;
-	}
-}
-
 __device__ __forceinline__ float halfArea(const float *box)
 {
 	float dx = box[4] - box[0], dy = box[5] - box[1], dz = box[6] - box[2];
@@ -386,7 +372,7 @@ __device__ __forceinline__ float halfArea(const float *box)
 
 __global__ void __launch_bounds__(kBlock)
     k_collapse_level(const CollapseTask *tasksIn, uint32_t nIn, CollapseTask *tasksOut, uint32_t *nOut, int n,
-                     const int2 *children, const int2 *range, const float *boxes, const uint32_t *sortedPrim,
+                     const int2 *children, const uint32_t *subCount, const float *boxes, const uint32_t *sortedPrim,
                      const PtVertex *verts, const uint32_t *indices, PtNode4 *nodes, uint32_t *nodeCount,
                      PtTri48 *tris, uint32_t *triCount, int leafMax)
 {
@@ -397,9 +383,7 @@ __global__ void __launch_bounds__(kBlock)
 	int slot[4];
 	int nSlots = 0;
 	{
-		int f, l;
-		nodeRange(task.bvh2, n, range, f, l);
-		if (l - f + 1 <= leafMax)
+		if ((int)subCount[task.bvh2] <= leafMax)
 			slot[nSlots++] = task.bvh2;  // whole subtree is one leaf child
 		else
 		{
@@ -413,9 +397,7 @@ __global__ void __launch_bounds__(kBlock)
 				float bestArea = -1.0f;
 				for (int s = 0; s < nSlots; ++s)
 				{
-					int f2, l2;
-					nodeRange(slot[s], n, range, f2, l2);
-					if (l2 - f2 + 1 <= leafMax) continue;  // stays a leaf child
+					if ((int)subCount[slot[s]] <= leafMax) continue;  // stays a leaf child
 					float a = halfArea(boxes + 8 * (size_t)slot[s]);
 					if (a > bestArea)
 					{
@@ -496,15 +478,28 @@ __global__ void __launch_bounds__(kBlock)
 			node.qlo[a] = (node.qlo[a] & ~(0xFFu << (8 * s))) | ((uint32_t)ql << (8 * s));
 			node.qhi[a] = (node.qhi[a] & ~(0xFFu << (8 * s))) | ((uint32_t)qh << (8 * s));
 		}
-		int f, l;
-		nodeRange(slot[s], n, range, f, l);
-		int cnt = l - f + 1;
+		int cnt = (int)subCount[slot[s]];
 		if (cnt <= leafMax)
 		{
+			// gather the primitives of the subtree, left to right (LBVH: ascending Morton order)
+			uint32_t prims[PT_LEAF_MAX];
+			int np = 0, dfs[PT_LEAF_MAX + 1], dsp = 0;
+			dfs[dsp++] = slot[s];
+			while (dsp > 0 && np < PT_LEAF_MAX)
+			{
+				int nd = dfs[--dsp];
+				if (nd >= n - 1) prims[np++] = sortedPrim[nd - (n - 1)];
+				else
+				{
+					int2 ch = children[nd];
+					dfs[dsp++] = ch.y;
+					dfs[dsp++] = ch.x;
+				}
+			}
 			uint32_t base = atomicAdd(triCount, (uint32_t)cnt);
 			for (int t = 0; t < cnt; ++t)
 			{
-				uint32_t prim = sortedPrim[f + t];
+				uint32_t prim = prims[t];
 				PtTri48 tr;
 				const float *p0 = verts[indices[3 * (size_t)prim + 0]].pos;
 				const float *p1 = verts[indices[3 * (size_t)prim + 1]].pos;
@@ -537,6 +532,139 @@ __global__ void __launch_bounds__(kBlock)
 		}
 	}
 	nodes[task.out] = node;
+}
+
+
+// subtree leaf counts of the LBVH (internal node i covers sorted positions range[i].x .. range[i].y)
+__global__ void __launch_bounds__(kBlock) k_lbvh_counts(const int2 *range, int n, uint32_t *subCount)
+{
+	int i = blockIdx.x * kBlock + threadIdx.x;
+	if (i < n - 1) subCount[i] = (uint32_t)(range[i].y - range[i].x + 1);
+	if (i < n) subCount[(n - 1) + i] = 1u;
+}
+
+// ----------------------------------------------------------------------------- PLOC ----
+// Parallel locally-ordered clustering (Meister & Bittner 2017) over the Morton-sorted leaves: every
+// cluster looks kPlocRadius positions to either side for the neighbour whose merged box has the least
+// surface area; mutual nearest neighbours merge; the survivors are compacted in order; repeat until
+// one cluster is left.  BVH2 node ids: leaf for sorted position k = (n-1)+k, internal nodes are numbered
+// 0.. in creation order (deterministic: exclusive scan of the merge flags), the root is the last one.
+constexpr int kPlocRadius = 16;
+
+__global__ void __launch_bounds__(kBlock) k_ploc_leaves(const float4 *triLo, const float4 *triHi,
+                                                        const uint32_t *sortedPrim, int n, const int *bounds,
+                                                        float *boxes, uint32_t *subCount, uint32_t *cluster)
+{
+	int k = blockIdx.x * kBlock + threadIdx.x;
+	if (k >= n) return;
+	const float pad = __uint_as_float((unsigned int)bounds[6]) * (1.0f / 262144.0f);  // as k_refit
+	uint32_t prim = sortedPrim[k];
+	float4 l4 = triLo[prim], h4 = triHi[prim];
+	float *b = boxes + 8 * (size_t)((n - 1) + k);
+	b[0] = l4.x - pad; b[1] = l4.y - pad; b[2] = l4.z - pad; b[3] = 0.0f;
+	b[4] = h4.x + pad; b[5] = h4.y + pad; b[6] = h4.z + pad; b[7] = 0.0f;
+	subCount[(n - 1) + k] = 1u;
+	cluster[k] = (uint32_t)((n - 1) + k);
+}
+
+__global__ void __launch_bounds__(kBlock) k_ploc_nearest(const uint32_t *cluster, uint32_t m, const float *boxes,
+                                                         uint32_t *nearest)
+{
+	uint32_t i = blockIdx.x * kBlock + threadIdx.x;
+	if (i >= m) return;
+	const float *bi = boxes + 8 * (size_t)cluster[i];
+	float lo[3] = { bi[0], bi[1], bi[2] }, hi[3] = { bi[4], bi[5], bi[6] };
+	uint32_t j0 = i > (uint32_t)kPlocRadius ? i - kPlocRadius : 0u;
+	uint32_t j1 = i + kPlocRadius < m - 1 ? i + kPlocRadius : m - 1;
+	float best = INFINITY;
+	uint32_t bestJ = i;
+	for (uint32_t j = j0; j <= j1; ++j)
+	{
+		if (j == i) continue;
+		const float *bj = boxes + 8 * (size_t)cluster[j];
+		float dx = fmaxf(hi[0], bj[4]) - fminf(lo[0], bj[0]);
+		float dy = fmaxf(hi[1], bj[5]) - fminf(lo[1], bj[1]);
+		float dz = fmaxf(hi[2], bj[6]) - fminf(lo[2], bj[2]);
+		float a = (dx * dy + dy * dz) + dz * dx;  // symmetric in (i, j): both sides compute the same value
+		if (a < best)
+		{
+			best = a;
+			bestJ = j;
+		}
+	}
+	nearest[i] = bestJ;
+}
+
+// keep[i] = cluster i survives at its position (alone, or as the merged pair's lower index);
+// merge[i] = cluster i is the lower index of a mutual pair and creates an internal node.
+__global__ void __launch_bounds__(kBlock) k_ploc_flags(const uint32_t *nearest, uint32_t m, uint32_t *keep,
+                                                       uint32_t *merge)
+{
+	uint32_t i = blockIdx.x * kBlock + threadIdx.x;
+	if (i >= m) return;
+	uint32_t j = nearest[i];
+	bool mutual = j != i && nearest[j] == i;
+	keep[i] = (mutual && j < i) ? 0u : 1u;
+	merge[i] = (mutual && i < j) ? 1u : 0u;
+}
+
+__global__ void __launch_bounds__(kBlock)
+    k_ploc_apply(const uint32_t *cluster, const uint32_t *nearest, uint32_t m, const uint32_t *keepScan,
+                 const uint32_t *mergeScan, uint32_t internalBase, float *boxes, uint32_t *subCount, int2 *children,
+                 uint32_t *clusterOut)
+{
+	uint32_t i = blockIdx.x * kBlock + threadIdx.x;
+	if (i >= m) return;
+	uint32_t j = nearest[i];
+	bool mutual = j != i && nearest[j] == i;
+	if (mutual && j < i) return;  // absorbed by its partner
+	uint32_t id = cluster[i];
+	if (mutual)
+	{
+		uint32_t a = id, b = cluster[j];
+		id = internalBase + mergeScan[i];
+		const float *ba = boxes + 8 * (size_t)a, *bb = boxes + 8 * (size_t)b;
+		float *bo = boxes + 8 * (size_t)id;
+		for (int k = 0; k < 3; ++k)
+		{
+			bo[k] = fminf(ba[k], bb[k]);
+			bo[4 + k] = fmaxf(ba[4 + k], bb[4 + k]);
+		}
+		bo[3] = bo[7] = 0.0f;
+		subCount[id] = subCount[a] + subCount[b];
+		children[id] = make_int2((int)a, (int)b);
+	}
+	clusterOut[keepScan[i]] = id;
+}
+
+// totals[0] = clusters left, totals[1] = merges of this iteration; run between the flags and the scans
+__global__ void __launch_bounds__(1024) k_ploc_totals(const uint32_t *keep, const uint32_t *merge, uint32_t m,
+                                                      uint32_t *totals)
+{
+	__shared__ uint32_t sk[1024], sm[1024];
+	uint32_t k = 0, g = 0;
+	for (uint32_t i = threadIdx.x; i < m; i += 1024)
+	{
+		k += keep[i];
+		g += merge[i];
+	}
+	sk[threadIdx.x] = k;
+	sm[threadIdx.x] = g;
+	__syncthreads();
+	for (int o = 512; o > 0; o >>= 1)
+	{
+		if ((int)threadIdx.x < o)
+		{
+			sk[threadIdx.x] += sk[threadIdx.x + o];
+			sm[threadIdx.x] += sm[threadIdx.x + o];
+		}
+		__syncthreads();
+	}
+	if (threadIdx.x == 0)
+	{
+		totals[0] = sk[0];
+		totals[1] = sm[0];
+	}
 }
 
 __global__ void k_init_bounds(int *bounds)
@@ -572,6 +700,9 @@ hipError_t ptBuildBvh4(const PtBuildInput &in, PtBuildOutput &out, hipStream_t s
 	int *parent = nullptr;
 	float *boxes = nullptr;
 	unsigned int *arrive = nullptr;
+	uint32_t *subCount = nullptr, *clusterA = nullptr, *clusterB = nullptr, *nearest = nullptr, *keep = nullptr,
+	         *merge = nullptr;
+	const bool ploc = in.builder == PT_BUILDER_PLOC;
 	CollapseTask *taskA = nullptr, *taskB = nullptr;
 	uint32_t *counters = nullptr;  // [0]=nodeCount [1]=triCount [2]=queue count
 	const uint32_t nSortBlocks = divUp(n, kTile);
@@ -593,6 +724,15 @@ hipError_t ptBuildBvh4(const PtBuildInput &in, PtBuildOutput &out, hipStream_t s
 	TRY(hipMalloc(&parent, sizeof(int) * nNodes2));
 	TRY(hipMalloc(&boxes, sizeof(float) * 8 * nNodes2));
 	TRY(hipMalloc(&arrive, sizeof(unsigned int) * n));
+	TRY(hipMalloc(&subCount, sizeof(uint32_t) * nNodes2));
+	if (ploc)
+	{
+		TRY(hipMalloc(&clusterA, 4 * (size_t)n));
+		TRY(hipMalloc(&clusterB, 4 * (size_t)n));
+		TRY(hipMalloc(&nearest, 4 * (size_t)n));
+		TRY(hipMalloc(&keep, 4 * (size_t)n));
+		TRY(hipMalloc(&merge, 4 * (size_t)n));
+	}
 	TRY(hipMalloc(&taskA, sizeof(CollapseTask) * n));
 	TRY(hipMalloc(&taskB, sizeof(CollapseTask) * n));
 	TRY(hipMalloc(&counters, sizeof(uint32_t) * 4));
@@ -629,17 +769,49 @@ hipError_t ptBuildBvh4(const PtBuildInput &in, PtBuildOutput &out, hipStream_t s
 		}
 		// after an even number of passes the sorted data is back in (keysA, valsA)
 		err = hipMemcpyAsync(order, vin, 4 * (size_t)n, hipMemcpyDeviceToDevice, stream);
-		TRY(hipMemsetAsync(arrive, 0, sizeof(unsigned int) * n, stream));
-		if (err == hipSuccess)
+		int rootNode = 0;  // LBVH: internal node 0 (or the only leaf, index 0, when n == 1)
+		if (err == hipSuccess && !ploc)
 		{
+			err = hipMemsetAsync(arrive, 0, sizeof(unsigned int) * n, stream);
 			if (n > 1) k_lbvh_topology<<<divUp(n - 1, kBlock), kBlock, 0, stream>>>(kin, (int)n, children, parent, range);
-			else err = hipMemsetAsync(parent, 0xFF, sizeof(int), stream);  // single leaf: parent = -1
+			else TRY(hipMemsetAsync(parent, 0xFF, sizeof(int), stream));  // single leaf: parent = -1
 			k_refit<<<gridTris, kBlock, 0, stream>>>(triLo, triHi, vin, (int)n, children, parent, bounds, boxes, arrive);
+			k_lbvh_counts<<<gridTris, kBlock, 0, stream>>>(range, (int)n, subCount);
+		}
+		if (err == hipSuccess && ploc)
+		{
+			k_ploc_leaves<<<gridTris, kBlock, 0, stream>>>(triLo, triHi, vin, (int)n, bounds, boxes, subCount, clusterA);
+			uint32_t m = n, created = 0;
+			uint32_t *cin = clusterA, *cout = clusterB;
+			while (err == hipSuccess && m > 1)
+			{
+				const uint32_t g = divUp(m, kBlock);
+				k_ploc_nearest<<<g, kBlock, 0, stream>>>(cin, m, boxes, nearest);
+				k_ploc_flags<<<g, kBlock, 0, stream>>>(nearest, m, keep, merge);
+				k_ploc_totals<<<1, 1024, 0, stream>>>(keep, merge, m, counters);
+				k_exclusive_scan<<<1, 1024, 0, stream>>>(keep, m);
+				k_exclusive_scan<<<1, 1024, 0, stream>>>(merge, m);
+				k_ploc_apply<<<g, kBlock, 0, stream>>>(cin, nearest, m, keep, merge, created, boxes, subCount, children,
+				                                       cout);
+				uint32_t h[2];
+				err = hipMemcpyAsync(h, counters, sizeof(h), hipMemcpyDeviceToHost, stream);
+				TRY(hipStreamSynchronize(stream));
+				if (err != hipSuccess) break;
+				// the globally closest pair inside the window is always mutual, so every pass merges at least once
+				if (h[1] == 0 || h[0] + h[1] != m || created + h[1] > n - 1) { err = hipErrorAssert; break; }
+				created += h[1];
+				m = h[0];
+				uint32_t *t = cin;
+				cin = cout;
+				cout = t;
+			}
+			rootNode = n > 1 ? (int)(created - 1) : 0;
+			if (err == hipSuccess && n > 1 && created != n - 1) err = hipErrorAssert;
 		}
 		// collapse, level by level (host reads the queue length between levels; one-time build)
 		uint32_t init[4] = { 1u, 0u, 0u, 0u };
 		TRY(hipMemcpyAsync(counters, init, sizeof(init), hipMemcpyHostToDevice, stream));
-		CollapseTask root = { 0, 0u };  // BVH2 root is internal node 0 (or the only leaf, index 0, when n == 1)
+		CollapseTask root = { rootNode, 0u };
 		TRY(hipMemcpyAsync(taskA, &root, sizeof(root), hipMemcpyHostToDevice, stream));
 		uint32_t nIn = 1;
 		CollapseTask *tin = taskA, *tout = taskB;
@@ -647,7 +819,7 @@ hipError_t ptBuildBvh4(const PtBuildInput &in, PtBuildOutput &out, hipStream_t s
 		{
 			++depth;
 			k_collapse_level<<<divUp(nIn, kBlock), kBlock, 0, stream>>>(tin, nIn, tout, counters + 2, (int)n, children,
-			                                                          range, boxes, vin, in.vertices, in.indices, nodes,
+			                                                          subCount, boxes, vin, in.vertices, in.indices, nodes,
 			                                                          counters, tris, counters + 1, leafMax);
 			uint32_t h[4];
 			err = hipMemcpyAsync(h, counters, sizeof(h), hipMemcpyDeviceToHost, stream);
@@ -676,6 +848,7 @@ hipError_t ptBuildBvh4(const PtBuildInput &in, PtBuildOutput &out, hipStream_t s
 #undef TRY
 	hipFree(triLo); hipFree(triHi); hipFree(bounds); hipFree(keysA); hipFree(keysB); hipFree(valsA); hipFree(valsB);
 	hipFree(hist); hipFree(children); hipFree(range); hipFree(parent); hipFree(boxes); hipFree(arrive);
+	hipFree(subCount); hipFree(clusterA); hipFree(clusterB); hipFree(nearest); hipFree(keep); hipFree(merge);
 	hipFree(taskA); hipFree(taskB); hipFree(counters);
 	if (err != hipSuccess)
 	{

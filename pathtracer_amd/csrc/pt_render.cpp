@@ -64,7 +64,7 @@ int main(int argc, char **argv)
 	}
 	CHECK(pt_upload_scene(ctx, pt_scene_vertices(sd), pt_scene_n_vertices(sd), pt_scene_indices(sd), pt_scene_n_indices(sd),
 	                      pt_scene_materials(sd), pt_scene_n_materials(sd), pt_scene_mat_indices(sd)));
-	CHECK(pt_build_accel(ctx, PT_ACCEL_BVH4));
+	CHECK(pt_build_accel(ctx, PT_ACCEL_BVH4_PLOC));
 	CHECK(pt_resize(ctx, W, H));
 	float view[16], proj[16];
 	pt_reference_camera(W, H, view, proj);

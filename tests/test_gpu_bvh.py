@@ -66,23 +66,28 @@ def validate_bvh(nodes, tris, scene):
     return depth_max
 
 
+BUILDERS = {"lbvh": 0, "ploc": 2}  # PT_ACCEL_BVH4, PT_ACCEL_BVH4_PLOC
+
+
+@pytest.mark.parametrize("builder", list(BUILDERS))
 @pytest.mark.parametrize("scene_name", ["cornell", "grid", "random", "single", "two", "five"])
-def test_bvh_structure(rt, pa, scene_name):
+def test_bvh_structure(rt, pa, scene_name, builder):
     sc = {"cornell": pa.scenes.cornell_box, "grid": lambda: pa.scenes.grid_mesh(40, 33),
           "random": lambda: pa.scenes.random_triangles(20000, extent=50.0, edge=1.0),
           "single": lambda: pa.scenes.random_triangles(0), "two": lambda: pa.scenes.random_triangles(0),
           "five": lambda: pa.scenes.random_triangles(3)}[scene_name]()
     if scene_name == "single":  # one triangle only
         sc = pa.Scene(sc.vertices, sc.indices[:3], sc.materials, sc.mat_indices[:1])
-    rt.buildBlas(sc)
+    rt.buildBlas(sc, BUILDERS[builder])
     nodes, tris = rt.debugReadBvh()
     depth = validate_bvh(nodes, tris, sc)
     st = rt.stats()
     assert st.bvh_nodes == len(nodes) and st.bvh_tris == sc.n_tris and st.bvh_depth == depth
 
 
+@pytest.mark.parametrize("builder", list(BUILDERS))
 @pytest.mark.parametrize("scene_name,n_rays", [("cornell", 400000), ("grid", 300000), ("random", 300000)])
-def test_bvh_traversal_equals_brute_force_definition(rt, pa, O, scene_name, n_rays):
+def test_bvh_traversal_equals_brute_force_definition(rt, pa, O, scene_name, n_rays, builder):
     """Incoherent rays (secondary-bounce-like), zero direction components included: GPU BVH4
     traversal == oracle (which is itself checked against brute force) == GPU brute force, bit for bit
     (t, u, v, primitive id)."""
@@ -96,12 +101,12 @@ def test_bvh_traversal_equals_brute_force_definition(rt, pa, O, scene_name, n_ra
     rays = random_rays(n_rays, lo, hi, seed=42)
     osc = O.OracleScene(sc.vertices, sc.indices, sc.materials, sc.mat_indices)
     want = osc.trace(rays)
-    rt.buildBlas(sc)
+    rt.buildBlas(sc, BUILDERS[builder])
     got = rt.debugTrace(rays)
     assert np.array_equal(got["prim"], want["prim"]), int((got["prim"] != want["prim"]).sum())
     assert np.array_equal(got.view(np.uint32), want.view(np.uint32))
     assert 0.05 < (got["prim"] != 0xFFFFFFFF).mean()
-    if sc.n_tris <= 20000:
+    if sc.n_tris <= 20000 and builder == "lbvh":
         rt.buildBlas(sc, PT_ACCEL_BRUTE_FORCE)
         sub = rays[:50000]
         assert np.array_equal(rt.debugTrace(sub).view(np.uint32), want[:50000].view(np.uint32))
