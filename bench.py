@@ -45,7 +45,7 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample-frames", type=int, default=1)
     ap.add_argument("--out-image", default="")
-    ap.add_argument("--pipeline", choices=["fused", "split"], default="fused")
+    ap.add_argument("--pipeline", choices=["persistent", "fused", "split"], default="fused")
     ap.add_argument("--builder", choices=["ploc", "lbvh"], default="ploc", help="BVH2 construction before the BVH4 collapse")
     ap.add_argument("--force-dist", action="store_true", help="initialise torch.distributed/RCCL even for one rank (rehearses the N>1 path on one GPU)")
     return ap.parse_args()
@@ -92,7 +92,7 @@ def main():
     first, stride = multigpu.frame_schedule(rank, world)
     rt.setFrameSchedule(first=first, stride=stride)
     rt.setAccumMode(PT_ACCUM_SUM if dist is not None else PT_ACCUM_MEAN)
-    rt.setPipeline(PT_PIPELINE_FUSED if a.pipeline == "fused" else PT_PIPELINE_SPLIT)
+    rt.setPipeline({"fused": PT_PIPELINE_FUSED, "split": PT_PIPELINE_SPLIT, "persistent": pa.api.PT_PIPELINE_PERSISTENT}[a.pipeline])
 
     def barrier():
         rt.synchronize()

@@ -148,6 +148,8 @@ int pt_set_accum_mode(pt_ctx *ctx, int mode);
  * flight); SPLIT = the classic wavefront pair k_extend / k_shade with the hit records in HBM. */
 #define PT_PIPELINE_FUSED 0
 #define PT_PIPELINE_SPLIT 1
+#define PT_PIPELINE_PERSISTENT 2 /* one persistent kernel per FRAME: waves generate camera rays, keep their paths
+                                   * from first ray to last (survivors in wave-private rings), no per-bounce launches */
 int pt_set_pipeline(pt_ctx *ctx, int mode);
 
 /* VulkanRaytracing::raytrace (VulkanRaytracing.cpp:868-901): ++frame, dispatch W x H x 1,

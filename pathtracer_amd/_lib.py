@@ -22,6 +22,7 @@ PT_PROFILE_KERNELS = 1
 PT_PROFILE_TRAVERSAL = 2
 PT_PIPELINE_FUSED = 0
 PT_PIPELINE_SPLIT = 1
+PT_PIPELINE_PERSISTENT = 2
 
 
 class PtStats(C.Structure):

@@ -15,7 +15,7 @@ import numpy as np
 
 from . import _lib
 from ._lib import (PT_ACCEL_BRUTE_FORCE, PT_ACCEL_BVH4, PT_ACCEL_BVH4_PLOC, PT_ACCUM_MEAN, PT_ACCUM_SUM, PT_NO_HIT, PT_PROFILE_KERNELS,
-                   PT_PROFILE_TRAVERSAL, PT_PIPELINE_FUSED, PT_PIPELINE_SPLIT, PtStats)
+                   PT_PROFILE_TRAVERSAL, PT_PIPELINE_FUSED, PT_PIPELINE_SPLIT, PT_PIPELINE_PERSISTENT, PtStats)
 
 HIT_DTYPE = np.dtype([("t", np.float32), ("u", np.float32), ("v", np.float32), ("prim", np.uint32)])
 NODE_DTYPE = np.dtype([("origin", np.float32, 3), ("exps", np.uint32), ("child", np.uint32, 4),
@@ -279,4 +279,4 @@ class HipRaytracing:
 
 __all__ = ["HipRaytracing", "PathTracerError", "Scene", "load_obj", "look_at", "perspective", "inverse4",
            "reference_camera", "HIT_DTYPE", "NODE_DTYPE", "TRI_DTYPE", "PT_ACCEL_BVH4", "PT_ACCEL_BVH4_PLOC", "PT_ACCEL_BRUTE_FORCE",
-           "PT_ACCUM_MEAN", "PT_ACCUM_SUM", "PT_NO_HIT", "PT_PROFILE_KERNELS", "PT_PROFILE_TRAVERSAL", "PT_PIPELINE_FUSED", "PT_PIPELINE_SPLIT", "PtStats"]
+           "PT_ACCUM_MEAN", "PT_ACCUM_SUM", "PT_NO_HIT", "PT_PROFILE_KERNELS", "PT_PROFILE_TRAVERSAL", "PT_PIPELINE_FUSED", "PT_PIPELINE_SPLIT", "PT_PIPELINE_PERSISTENT", "PtStats"]

@@ -62,6 +62,8 @@ struct pt_ctx
 	PtFrameCounters *counters = nullptr;
 	unsigned long long *dStats = nullptr;  // [0] rays_total [1] rays_last_frame [2..4] traversal counters
 	PtLaunchCfg cfg = {};
+	uint2 *dLcgSkip = nullptr;  // persistent pipeline: LCG skip-ahead pairs for 0, 2, 4, .. steps
+	int lcgSkipSpp = 0;
 
 	int profiling = 0;
 	std::vector<EventPair> pending;
@@ -148,7 +150,7 @@ int ensureQueues(pt_ctx *c, size_t records)
 		PT_HIP(c, hipMalloc(&c->q.chunkCount[i], chunks * sizeof(uint32_t)));
 	}
 	PT_HIP(c, hipMalloc(&c->q.hits, bytes));
-	PT_HIP(c, hipMalloc(&c->q.rad, bytes));
+	PT_HIP(c, hipMalloc(&c->q.rad, qbytes));  // item-major layout of the persistent pipeline pads the last pixel group
 	c->queueCap = records;
 	return PT_OK;
 }
@@ -303,6 +305,7 @@ extern "C" void pt_destroy(pt_ctx *c)
 	hipFree(c->dStats);
 	hipFree(c->cfg.spill);
 	hipFree(c->cfg.waveRays);
+	hipFree(c->dLcgSkip);
 	if (c->ownStream) hipStreamDestroy(c->ownStream);
 	delete c;
 }
@@ -473,14 +476,82 @@ extern "C" int pt_render_frame(pt_ctx *c)
 	PT_HIP(c, hipSetDevice(c->device));
 	const uint32_t WH = c->W * c->H;
 	const size_t nPaths = (size_t)WH * c->spp;
-	rc = ensureQueues(c, nPaths);
+	const bool persistent = (c->pipeline == PT_PIPELINE_PERSISTENT) && !c->brute;
+	const size_t nPadded = (size_t)((WH + PT_WAVE - 1) / PT_WAVE) * PT_WAVE * c->spp;  // whole pixel groups of 64
+	if (nPadded > 0xFFFFFF00ull) return fail(c, PT_EINVAL, "pt_render_frame: %zu paths per frame exceed 2^32", nPadded);
+	rc = ensureQueues(c, persistent ? nPadded : nPaths);
 	if (rc) return rc;
+	if (persistent && c->lcgSkipSpp != c->spp)
+	{
+		// lcg^(2i)(s) = A_i * s + C_i (mod 2^32): lets a wave enter a pixel's seed chain at sample i (rgen:28-37)
+		std::vector<uint2> tab((size_t)c->spp);
+		uint32_t A = 1u, C = 0u;
+		for (int i = 0; i < c->spp; ++i)
+		{
+			tab[(size_t)i] = make_uint2(A, C);
+			for (int k = 0; k < 2; ++k)
+			{
+				A = 1664525u * A;
+				C = 1664525u * C + 1013904223u;
+			}
+		}
+		PT_HIP(c, hipStreamSynchronize(c->stream));  // frames in flight still read the old table
+		hipFree(c->dLcgSkip);
+		c->dLcgSkip = nullptr;
+		PT_HIP(c, hipMalloc(&c->dLcgSkip, sizeof(uint2) * tab.size()));
+		PT_HIP(c, hipMemcpy(c->dLcgSkip, tab.data(), sizeof(uint2) * tab.size(), hipMemcpyHostToDevice));
+		c->lcgSkipSpp = c->spp;
+	}
 	const uint32_t gframe = c->firstFrame + (uint32_t)c->frame * c->frameStride;
 	hipStream_t s = c->stream;
 	PtSceneDev sc = sceneDev(c);
 	const bool fused = (c->pipeline == PT_PIPELINE_FUSED) && !c->brute;
 	unsigned long long *trav = (c->profiling & PT_PROFILE_TRAVERSAL) ? c->dStats + 2 : nullptr;
 	ptLaunchFrameBegin(c->counters, (uint32_t)nPaths, fused ? 1 : 0, s);
+	if (persistent)
+	{
+		hipEvent_t e0 = nullptr, e1 = nullptr, e2 = nullptr;
+		if (c->profiling & PT_PROFILE_KERNELS)
+		{
+			e0 = getEvent(c);
+			e1 = getEvent(c);
+			e2 = getEvent(c);
+			hipEventRecord(e0, s);
+		}
+		PtPathsArgs pa;
+		pa.sc = sc;
+		pa.cam = c->cam;
+		pa.W = c->W;
+		pa.H = c->H;
+		pa.spp = (uint32_t)c->spp;
+		pa.seedWord = c->seed + gframe;
+		pa.centreJitter = gframe == 0;
+		pa.maxDepth = c->maxDepth;
+		pa.tmin = c->tmin;
+		pa.tmax = c->tmax;
+		pa.lcgSkip = c->dLcgSkip;
+		pa.ringO = c->q.rayO[0];
+		pa.ringD = c->q.rayD[0];
+		pa.state = c->q.thr[0];
+		pa.rad = c->q.rad;
+		pa.itemHead = &c->counters->chunkHead[0];
+		pa.waveRays = c->cfg.waveRays;
+		pa.spill = c->cfg.spill;
+		pa.spillStride = c->cfg.spillStride;
+		pa.trav = trav;
+		ptLaunchPaths(pa, c->cfg.bounceWaves, trav != nullptr, s);
+		if (e1) hipEventRecord(e1, s);
+		ptLaunchAccumulateItems(c->q.rad, WH, (uint32_t)c->spp, c->image, (uint32_t)c->frame, c->accumMode, s);
+		if (e2)
+		{
+			hipEventRecord(e2, s);
+			c->pending.push_back({ e0, e1, e2 });
+		}
+		ptLaunchFrameEnd(c->counters, 0, c->dStats, c->cfg.waveRays, c->cfg.bounceWaves, s);
+		PT_HIP(c, hipGetLastError());
+		c->framesRendered++;
+		return PT_OK;
+	}
 	ptLaunchGenerate(c->cam, c->W, c->H, (uint32_t)c->spp, c->seed + gframe, gframe == 0, c->q, s);
 	int in = 0;
 	for (int d = 0; d < c->maxDepth; ++d)
@@ -524,7 +595,7 @@ extern "C" int pt_render_frame(pt_ctx *c)
 extern "C" int pt_set_pipeline(pt_ctx *c, int mode)
 {
 	if (!c) return fail(nullptr, PT_EINVAL, "null context");
-	if (mode != PT_PIPELINE_FUSED && mode != PT_PIPELINE_SPLIT) return fail(c, PT_EINVAL, "pt_set_pipeline: bad mode %d", mode);
+	if (mode != PT_PIPELINE_FUSED && mode != PT_PIPELINE_SPLIT && mode != PT_PIPELINE_PERSISTENT) return fail(c, PT_EINVAL, "pt_set_pipeline: bad mode %d", mode);
 	c->pipeline = mode;
 	return PT_OK;
 }

@@ -17,6 +17,7 @@
 // All arithmetic that reaches a result is the shared specification of pt_device_common.h, so
 // images stay bit-identical to the split pipeline and to the CPU oracle.
 #include "pt_trace.h"
+#include "pt_wave_traverse.h"
 
 #ifndef PT_NODE_WEIGHT
 #define PT_NODE_WEIGHT 1u
@@ -257,41 +258,17 @@ __global__ void __launch_bounds__(PT_WAVE)
 						uint32_t ridx = chunkBase + chunkPos + lane;
 						float4 ro = rayOIn[ridx], rd = rayDIn[ridx];
 						float3x d = { rd.x, rd.y, rd.z };
-						// dominant axis kz; the other two follow cyclically (kx = kz+1, ky = kz+2 mod 3).  Woop's
-						// winding swap for d[kz] < 0 is omitted: it negates U, V, W, det and T exactly and leaves
-						// t, u, v unchanged, so results equal the oracle's (which keeps the swap) bit for bit.
-						float ad0 = fabsf(d.x), ad1 = fabsf(d.y), ad2 = fabsf(d.z);
-						uint32_t kz = 0;
-						float am = ad0;
-						if (ad1 > am)
-						{
-							kz = 1;
-							am = ad1;
-						}
-						if (ad2 > am) kz = 2;
-						float dkz = kz == 0 ? d.x : (kz == 1 ? d.y : d.z);
-						float dkx = kz == 0 ? d.y : (kz == 1 ? d.z : d.x);
-						float dky = kz == 0 ? d.z : (kz == 1 ? d.x : d.y);
-						PtRayShear rs;
-						rs.Sx = dkx / dkz;
-						rs.Sy = dky / dkz;
-						rs.Sz = 1.0f / dkz;
-						// box test only: zero components nudged so that 0 * inf cannot occur (interval stays huge)
-						float dcx = fabsf(d.x) > 1e-30f ? d.x : copysignf(1e-30f, d.x);
-						float dcy = fabsf(d.y) > 1e-30f ? d.y : copysignf(1e-30f, d.y);
-						float dcz = fabsf(d.z) > 1e-30f ? d.z : copysignf(1e-30f, d.z);
-						float rx = 1.0f / dcx, ry = 1.0f / dcy, rz = 1.0f / dcz;
-						uint32_t kp = kz | ((rx < 0.0f) ? 64u : 0u) | ((ry < 0.0f) ? 128u : 0u) | ((rz < 0.0f) ? 256u : 0u);
+						PtLaneRay pr = pt_prepare_ray({ ro.x, ro.y, ro.z }, d);
 						sIn[0][lane] = __float_as_uint(ro.x);
 						sIn[1][lane] = __float_as_uint(ro.y);
 						sIn[2][lane] = __float_as_uint(ro.z);
-						sIn[3][lane] = __float_as_uint(rx);
-						sIn[4][lane] = __float_as_uint(ry);
-						sIn[5][lane] = __float_as_uint(rz);
-						sIn[6][lane] = __float_as_uint(rs.Sx);
-						sIn[7][lane] = __float_as_uint(rs.Sy);
-						sIn[8][lane] = __float_as_uint(rs.Sz);
-						sIn[9][lane] = kp;
+						sIn[3][lane] = __float_as_uint(pr.ix);
+						sIn[4][lane] = __float_as_uint(pr.iy);
+						sIn[5][lane] = __float_as_uint(pr.iz);
+						sIn[6][lane] = __float_as_uint(pr.Sx);
+						sIn[7][lane] = __float_as_uint(pr.Sy);
+						sIn[8][lane] = __float_as_uint(pr.Sz);
+						sIn[9][lane] = pr.kpack;
 						sIn[10][lane] = __float_as_uint(ro.w);
 						sIn[11][lane] = __float_as_uint(rd.w);
 						sIn[12][lane] = ridx;
@@ -344,150 +321,14 @@ __global__ void __launch_bounds__(PT_WAVE)
 		const unsigned long long nodeLanes = __ballot(!(cur & PT_LEAF_FLAG));
 		const unsigned long long leafLanes = __ballot((cur & PT_LEAF_FLAG) && cur != PT_TRAVERSAL_DONE);
 		const bool doNode = popc64(nodeLanes) * PT_NODE_WEIGHT >= popc64(leafLanes) * PT_LEAF_WEIGHT;
+		const PtLaneRay ray = { ox, oy, oz, ix, iy, iz, Sx, Sy, Sz, kpack };
 		if (doNode && !(cur & PT_LEAF_FLAG))
 		{
 			if (kStats) ++nodeFetches;
-			const uint4 *np = reinterpret_cast<const uint4 *>(sc.nodes + cur);
-			uint4 n0 = np[0], n1 = np[1], n2 = np[2], n3 = np[3];
-			// the entry that is popped if no child is hit; read early so its latency hides under the box tests
-			const bool fastStack = sp <= kStackLds - 3;
-			uint32_t top = sStack[sp - 1 < kStackLds ? sp - 1 : 0][lane];
-			float sx = __uint_as_float((n0.w & 0xFFu) << 23), sy = __uint_as_float(((n0.w >> 8) & 0xFFu) << 23),
-			      sz = __uint_as_float(((n0.w >> 16) & 0xFFu) << 23);
-			float ax = sx * ix, ay = sy * iy, az = sz * iz;
-			float bx = (__uint_as_float(n0.x) - ox) * ix, by = (__uint_as_float(n0.y) - oy) * iy,
-			      bz = (__uint_as_float(n0.z) - oz) * iz;
-			const bool negx = kpack & 64u, negy = kpack & 128u, negz = kpack & 256u;
-			// n2 = qlo[0..2], qhi[0]; n3 = qhi[1..2], pad
-			uint32_t nqx = negx ? n2.w : n2.x, fqx = negx ? n2.x : n2.w;
-			uint32_t nqy = negy ? n3.x : n2.y, fqy = negy ? n2.y : n3.x;
-			uint32_t nqz = negz ? n3.y : n2.z, fqz = negz ? n2.z : n3.y;
-			uint32_t ref[4] = { n1.x, n1.y, n1.z, n1.w };
-			float tn[4];
-#pragma unroll
-			for (int c = 0; c < 4; ++c)
-			{
-				float tnx = __builtin_fmaf((float)((nqx >> (8 * c)) & 0xFFu), ax, bx);
-				float tny = __builtin_fmaf((float)((nqy >> (8 * c)) & 0xFFu), ay, by);
-				float tnz = __builtin_fmaf((float)((nqz >> (8 * c)) & 0xFFu), az, bz);
-				float tfx = __builtin_fmaf((float)((fqx >> (8 * c)) & 0xFFu), ax, bx);
-				float tfy = __builtin_fmaf((float)((fqy >> (8 * c)) & 0xFFu), ay, by);
-				float tfz = __builtin_fmaf((float)((fqz >> (8 * c)) & 0xFFu), az, bz);
-				float t0 = fmaxf(fmaxf(tnx, tny), fmaxf(tnz, tmin));
-				float t1 = fminf(fminf(tfx, tfy), fminf(tfz, best.t));
-				bool hit = (t0 <= t1 * 1.000001f) && (ref[c] != PT_EMPTY_CHILD);
-				tn[c] = hit ? t0 : INFINITY;
-			}
-			// sort the (entry distance, reference) pairs ascending: 5 compare-exchanges; missed children (inf) sink
-#define PT_CE(a, b)                         \
-	{                                       \
-		bool sw_ = tn[b] < tn[a];           \
-		float tl_ = sw_ ? tn[b] : tn[a];    \
-		float th_ = sw_ ? tn[a] : tn[b];    \
-		uint32_t rl_ = sw_ ? ref[b] : ref[a]; \
-		uint32_t rh_ = sw_ ? ref[a] : ref[b]; \
-		tn[a] = tl_;                        \
-		tn[b] = th_;                        \
-		ref[a] = rl_;                       \
-		ref[b] = rh_;                       \
-	}
-			PT_CE(0, 1) PT_CE(2, 3) PT_CE(0, 2) PT_CE(1, 3) PT_CE(1, 2)
-#undef PT_CE
-			const bool h0 = tn[0] < INFINITY, h1 = tn[1] < INFINITY, h2 = tn[2] < INFINITY, h3 = tn[3] < INFINITY;
-			if (fastStack)
-			{
-				// branch-free: far children are stored unconditionally above the top, the stack pointer only
-				// moves past the ones that were hit (far -> near, so the nearest pending child is popped first)
-				sStack[sp][lane] = ref[3];
-				sp += h3 ? 1 : 0;
-				sStack[sp][lane] = ref[2];
-				sp += h2 ? 1 : 0;
-				sStack[sp][lane] = ref[1];
-				sp += h1 ? 1 : 0;
-				cur = h0 ? ref[0] : top;
-				sp -= h0 ? 0 : 1;
-			}
-			else
-			{
-#define PT_PUSH(v)                                                                                         \
-	{                                                                                                      \
-		if (sp < kStackLds) sStack[sp][lane] = (v);                                                        \
-		else if (sp < kStackLds + PT_SPILL_STACK) mySpill[(size_t)(sp - kStackLds) * spillStride] = (v);   \
-		++sp;                                                                                              \
-	}
-				if (h3) PT_PUSH(ref[3]);
-				if (h2) PT_PUSH(ref[2]);
-				if (h1) PT_PUSH(ref[1]);
-#undef PT_PUSH
-				if (h0) cur = ref[0];
-				else
-				{
-					--sp;
-					cur = sp < kStackLds ? sStack[sp][lane]
-					                     : (sp < kStackLds + PT_SPILL_STACK ? mySpill[(size_t)(sp - kStackLds) * spillStride]
-					                                                        : PT_EMPTY_CHILD);
-				}
-			}
+			pt_node_step<kStackLds>(sc, ray, tmin, best, cur, sp, sStack, lane, mySpill, spillStride);
 		}
 		if (!doNode && (cur & PT_LEAF_FLAG) && cur != PT_TRAVERSAL_DONE)
-		{
-			// the next entry is needed whatever the triangles say: read it first
-			--sp;
-			uint32_t next = sp < kStackLds ? sStack[sp][lane]
-			                               : (sp < kStackLds + PT_SPILL_STACK ? mySpill[(size_t)(sp - kStackLds) * spillStride]
-			                                                                  : PT_EMPTY_CHILD);
-			if (cur != PT_EMPTY_CHILD)
-			{
-				const uint32_t kz = kpack & 3u;
-				// origin in the triangle plane's axis order (kx, ky, kz)
-				float rox = kz == 0 ? oy : (kz == 1 ? oz : ox);
-				float roy = kz == 0 ? oz : (kz == 1 ? ox : oy);
-				float roz = kz == 0 ? ox : (kz == 1 ? oy : oz);
-				uint32_t first = cur & 0x0FFFFFFFu;
-				uint32_t cnt = ((cur >> 28) & 7u) + 1u;
-				if (kStats) triTests += cnt;
-				const float4 *tp = reinterpret_cast<const float4 *>(sc.tris + (size_t)kz * sc.nTris + first);
-				for (uint32_t i = 0; i < cnt; ++i, tp += 3)
-				{
-					float4 a = tp[0], b = tp[1], c = tp[2];
-					// Woop/Benthin/Wald watertight test in the rotated frame (pt_tri_test without the selects)
-					float Akx = a.x - rox, Aky = a.y - roy, Akz = a.z - roz;
-					float Bkx = a.w - rox, Bky = b.x - roy, Bkz = b.y - roz;
-					float Ckx = b.z - rox, Cky = b.w - roy, Ckz = c.x - roz;
-					float Ax = Akx - Sx * Akz, Ay = Aky - Sy * Akz;
-					float Bx = Bkx - Sx * Bkz, By = Bky - Sy * Bkz;
-					float Cx = Ckx - Sx * Ckz, Cy = Cky - Sy * Ckz;
-					float U = Cx * By - Cy * Bx;
-					float V = Ax * Cy - Ay * Cx;
-					float W = Bx * Ay - By * Ax;
-					if (U == 0.0f || V == 0.0f || W == 0.0f)
-					{
-						U = (float)((double)Cx * (double)By - (double)Cy * (double)Bx);
-						V = (float)((double)Ax * (double)Cy - (double)Ay * (double)Cx);
-						W = (float)((double)Bx * (double)Ay - (double)By * (double)Ax);
-					}
-					bool anyNeg = U < 0.0f || V < 0.0f || W < 0.0f, anyPos = U > 0.0f || V > 0.0f || W > 0.0f;
-					float det = (U + V) + W;
-					if (!(anyNeg && anyPos) && det != 0.0f)
-					{
-						float Az = Sz * Akz, Bz = Sz * Bkz, Cz = Sz * Ckz;
-						float T = (U * Az + V * Bz) + W * Cz;
-						float t = T / det;
-						uint32_t prim = __float_as_uint(c.y);
-						if (t > tmin && (t < best.t || (t == best.t && best.prim != PT_NO_HIT && prim < best.prim)))
-						{
-							best.t = t;
-							best.prim = prim;
-							best.V = V;
-							best.W = W;
-							best.det = det;
-						}
-					}
-				}
-			}
-			cur = next;
-		}
-
+			pt_leaf_step<kStackLds>(sc, ray, tmin, best, cur, sp, sStack, lane, mySpill, spillStride, triTests);
 	}
 	// drain the ring
 	__syncthreads();

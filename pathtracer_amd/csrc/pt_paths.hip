@@ -1,0 +1,418 @@
+// k_paths: a whole frame of paths in ONE persistent kernel -- raytrace.rgen:28-80 (seed, jitter, camera
+// ray, the bounce loop), traceRayEXT, raytrace.rchit / raytrace.rmiss -- "path regeneration inside the wave".
+//
+// Why.  With one k_bounce launch per bounce (pt_bounce.hip) every bounce pays a tail (waves finish a claim
+// of >= 256 rays ~ 60 us apart: measured ~80 us fixed cost per launch, 10 % of the frame), k_generate is a
+// separate HBM-bound pass (6 %), and all survivors make a round trip through global chunked queues.  Here
+//   * a wave generates its primary rays itself, 64 at a time at full lane utilisation (the staging phase
+//     of k_bounce), from work items claimed with one atomic per up to 16 items;
+//   * lanes whose traversal ended are refilled inside the wave, finished hits are parked in an LDS ring
+//     and shaded 64 at a time (both exactly as in k_bounce);
+//   * survivors of the shading go to a small WAVE-PRIVATE ring in global memory (256 records, no atomics,
+//     no chunk bookkeeping) and come back through the staging phase, preferred over new paths -- so a path
+//     stays in the wave that started it from its first ray to its last;
+//   * the per-path state that is only needed at a hit (throughput, rng state) lives in one 16-byte record
+//     state[q], the radiance in rad[q], q = item * 64 + lane: a staging batch touches 1 KB contiguous.
+// One tail per frame instead of one per bounce.  Every arithmetic step that reaches a result is the shared
+// specification (pt_device_common.h, pt_wave_traverse.h): images are bit-identical to the other pipelines
+// and to the CPU oracle.
+//
+// Work item = (pixel group g of 64 consecutive pixels, sample i): item = g * spp + i.  The raygen seed chain
+// of a pixel is sequential over its samples (rgen:28-37: seed = tea(pixel, frame); two rnd() per sample); a
+// wave that processes consecutive items of one group continues the chain in a register, a wave that starts
+// in the middle of a group (claims are not aligned to groups) jumps there with the LCG skip-ahead pair
+// (A^2i, C_2i) from a table the host computes.
+#include "pt_trace.h"
+#include "pt_wave_traverse.h"
+
+#ifndef PT_PATHS_MIN_ITEMS
+#define PT_PATHS_MIN_ITEMS 2u
+#endif
+#ifndef PT_PATHS_MAX_ITEMS
+#define PT_PATHS_MAX_ITEMS 16u
+#endif
+#ifndef PT_REFILL_LANES
+#define PT_REFILL_LANES 16
+#endif
+
+namespace
+{
+constexpr int kStackLds = 12;   // traversal stack entries per lane held in LDS; deeper ones spill to global
+constexpr int kInFields = 11;   // ox oy oz ix iy iz Sx Sy Sz kpack(kz | signs | depth << 16) q
+constexpr int kDoneFields = 6;  // V W det prim q kpack
+constexpr int kDoneRing = 128;
+constexpr uint32_t kRefillLanes = PT_REFILL_LANES;
+constexpr uint32_t kNoPath = 0xFFFFFFFFu;
+
+__device__ __forceinline__ uint32_t popc64(unsigned long long m) { return (uint32_t)__popcll(m); }
+
+template <bool kStats>
+__global__ void __launch_bounds__(PT_WAVE) k_paths(PtPathsArgs a)
+{
+	__shared__ uint32_t sStack[kStackLds][PT_WAVE];
+	__shared__ uint32_t sIn[kInFields][PT_WAVE];
+	__shared__ uint32_t sDone[kDoneFields][kDoneRing];
+
+	const PtSceneDev &sc = a.sc;
+	const int lane = threadIdx.x;
+	const unsigned long long laneBit = 1ull << lane, lanesBelow = laneBit - 1ull;
+	uint32_t *mySpill = a.spill + (size_t)blockIdx.x * PT_WAVE + lane;
+	const float tmin = a.tmin, tmax = a.tmax;
+	const uint32_t WH = a.W * a.H;
+	const uint32_t totalItems = ((WH + PT_WAVE - 1) / PT_WAVE) * a.spp;
+
+	// ---- generator (wave-uniform cursors + the per-lane raygen seed chain) ----
+	const uint32_t firstShare = totalItems / (2u * gridDim.x);
+	const uint32_t firstK = firstShare >= PT_PATHS_MAX_ITEMS ? PT_PATHS_MAX_ITEMS : (firstShare == 0 ? 1u : firstShare);
+	const uint32_t headBias = gridDim.x * firstK;  // items handed out statically (first claim of every wave)
+	bool firstClaim = true, genDone = (totalItems == 0), needSeed = true;
+	uint32_t lastSeen = headBias, itemCur = 0, itemEnd = 0;
+	uint32_t genSeed = 0, genPx = 0, genPy = 0;
+	bool genValid = false;
+
+	// ---- wave-private survivor ring in global memory ----
+	float4 *ringO = a.ringO + (size_t)blockIdx.x * PT_PATHS_RING;
+	float4 *ringD = a.ringD + (size_t)blockIdx.x * PT_PATHS_RING;
+	uint32_t ringHead = 0, ringCount = 0;
+
+	uint32_t inCount = 0, inPos = 0;      // prepared rays in sIn
+	uint32_t doneHead = 0, doneTail = 0;  // LDS ring of finished rays
+	uint32_t raysFetched = 0;
+	uint32_t nodeFetches = 0, triTests = 0, nHits = 0;
+
+	// per-lane ray state
+	float ox = 0, oy = 0, oz = 0, ix = 0, iy = 0, iz = 0, Sx = 0, Sy = 0, Sz = 0;
+	uint32_t kpack = 0, q = kNoPath;
+	PtBest best = { tmax, PT_NO_HIT, 0.0f, 0.0f, 1.0f };
+	uint32_t cur = PT_TRAVERSAL_DONE;
+	int sp = 0;
+
+	// Shades `count` (<= 64) parked hits and sends the survivors to the wave's ring.
+	auto flush = [&](uint32_t count) {
+		bool alive = false;
+		float3x no = { 0, 0, 0 }, nd = { 0, 0, 0 };
+		uint32_t pq = 0, depth = 0;
+		if ((uint32_t)lane < count)
+		{
+			uint32_t e = (doneHead + lane) & (kDoneRing - 1);
+			uint32_t prim = sDone[3][e];
+			pq = sDone[4][e];
+			depth = sDone[5][e] >> 16;
+			if (prim != PT_NO_HIT)  // rmiss: hitValue = 0, emission = 0, terminate -> nothing to do
+			{
+				float V = __uint_as_float(sDone[0][e]), W = __uint_as_float(sDone[1][e]), det = __uint_as_float(sDone[2][e]);
+				float u = V / det, v = W / det;
+				float4 T = a.state[pq];  // throughput, rng state
+				uint32_t seed = __float_as_uint(T.w);
+				const float *mat;
+				pt_shade_hit(sc, prim, u, v, seed, no, nd, mat);
+				float ex = mat[3], ey = mat[4], ez = mat[5];
+				if (ex != 0.0f || ey != 0.0f || ez != 0.0f)
+				{
+					// accumDepthHitValue += emission * curAttenuation (rgen:78); one thread owns a path
+					float4 L = a.rad[pq];
+					L.x += ex * T.x;
+					L.y += ey * T.y;
+					L.z += ez * T.z;
+					a.rad[pq] = L;
+				}
+				alive = (int)(depth + 1) < a.maxDepth && !((ex + ey) + ez > 0.0f);  // rgen:61 loop bound, rchit:56-58
+				if (alive)  // curAttenuation *= hitValue (rgen:79)
+					a.state[pq] = make_float4(T.x * mat[0], T.y * mat[1], T.z * mat[2], __uint_as_float(seed));
+				if (kStats) ++nHits;
+			}
+		}
+		doneHead += count;
+		unsigned long long am = __ballot(alive);
+		if (alive)
+		{
+			uint32_t slot = (ringHead + ringCount + popc64(am & lanesBelow)) & (PT_PATHS_RING - 1);
+			ringO[slot] = make_float4(no.x, no.y, no.z, __uint_as_float(depth + 1));
+			ringD[slot] = make_float4(nd.x, nd.y, nd.z, __uint_as_float(pq));
+		}
+		ringCount += popc64(am);
+	};
+
+	// Writes lane's prepared ray into the staging area.
+	auto stage = [&](float3x o, float3x d, uint32_t depth, uint32_t pq) {
+		PtLaneRay pr = pt_prepare_ray(o, d);
+		sIn[0][lane] = __float_as_uint(pr.ox);
+		sIn[1][lane] = __float_as_uint(pr.oy);
+		sIn[2][lane] = __float_as_uint(pr.oz);
+		sIn[3][lane] = __float_as_uint(pr.ix);
+		sIn[4][lane] = __float_as_uint(pr.iy);
+		sIn[5][lane] = __float_as_uint(pr.iz);
+		sIn[6][lane] = __float_as_uint(pr.Sx);
+		sIn[7][lane] = __float_as_uint(pr.Sy);
+		sIn[8][lane] = __float_as_uint(pr.Sz);
+		sIn[9][lane] = pr.kpack | (depth << 16);
+		sIn[10][lane] = pq;
+	};
+
+	for (;;)
+	{
+		// Retire + refill only when enough lanes wait for it (or nothing else is left to do): the section
+		// costs about half a node step, so it is not run for every single finished lane.
+		const uint32_t nIdle = popc64(__ballot(cur == PT_TRAVERSAL_DONE));
+		if (nIdle >= kRefillLanes)
+		{
+			// ------------------------------------------------------------------ C: retire finished lanes ----
+			bool fin = (q != kNoPath) && (cur == PT_TRAVERSAL_DONE);
+			unsigned long long fm = __ballot(fin);
+			if (fm)
+			{
+				if (fin)
+				{
+					uint32_t e = (doneTail + popc64(fm & lanesBelow)) & (kDoneRing - 1);
+					sDone[0][e] = __float_as_uint(best.V);
+					sDone[1][e] = __float_as_uint(best.W);
+					sDone[2][e] = __float_as_uint(best.det);
+					sDone[3][e] = best.prim;
+					sDone[4][e] = q;
+					sDone[5][e] = kpack;
+					q = kNoPath;
+				}
+				doneTail += popc64(fm);
+				if (doneTail - doneHead >= PT_WAVE)
+				{
+					__syncthreads();
+					flush(PT_WAVE);
+					__syncthreads();
+				}
+			}
+			// ------------------------------------------------------------------ A: refill idle lanes ----
+			unsigned long long idle = __ballot(cur == PT_TRAVERSAL_DONE);
+			while (idle)
+			{
+				if (inPos == inCount)
+				{
+					uint32_t n = 0;
+					if (ringCount >= PT_WAVE || (genDone && ringCount > 0))
+					{
+						// continue paths of this wave: the next (up to) 64 survivors
+						n = ringCount < PT_WAVE ? ringCount : PT_WAVE;
+						__syncthreads();  // staging contents consumed; ring stores of earlier flushes complete
+						if ((uint32_t)lane < n)
+						{
+							uint32_t slot = (ringHead + lane) & (PT_PATHS_RING - 1);
+							float4 ro = ringO[slot], rd = ringD[slot];
+							stage({ ro.x, ro.y, ro.z }, { rd.x, rd.y, rd.z }, __float_as_uint(ro.w), __float_as_uint(rd.w));
+						}
+						ringHead += n;
+						ringCount -= n;
+					}
+					else if (!genDone)
+					{
+						if (itemCur == itemEnd)
+						{
+							// Guided self-scheduling over the work items: a static first claim, then one atomic for
+							// clamp(remaining / (2 * waves), MIN, MAX) items; the wave never polls the counter, it uses
+							// the value its own previous claim returned.
+							uint32_t c, k;
+							if (firstClaim)
+							{
+								firstClaim = false;
+								k = firstK;
+								c = blockIdx.x * firstK;
+							}
+							else
+							{
+								if (lastSeen >= totalItems)
+								{
+									genDone = true;
+									continue;
+								}
+								const uint32_t share = (totalItems - lastSeen) / (2u * gridDim.x);
+								k = share >= PT_PATHS_MAX_ITEMS ? PT_PATHS_MAX_ITEMS
+								                                : (share <= PT_PATHS_MIN_ITEMS ? PT_PATHS_MIN_ITEMS : share);
+								c = 0;
+								if (lane == 0) c = atomicAdd(a.itemHead, k);
+								c = __builtin_amdgcn_readfirstlane(c) + headBias;
+							}
+							if (c >= totalItems)
+							{
+								genDone = true;
+								continue;
+							}
+							lastSeen = c + k;
+							itemCur = c;
+							itemEnd = c + k < totalItems ? c + k : totalItems;
+							needSeed = true;
+						}
+						const uint32_t item = itemCur++;
+						const uint32_t g = item / a.spp, i = item - g * a.spp;
+						if (needSeed || i == 0)
+						{
+							needSeed = false;
+							uint32_t p = g * PT_WAVE + lane;
+							genValid = p < WH;
+							genPy = p / a.W;
+							genPx = p - genPy * a.W;
+							genSeed = pt_tea(p, a.seedWord);  // rgen:28 with val1 = seed + global frame
+							if (i)
+							{
+								uint2 ac = a.lcgSkip[i];  // state after 2*i lcg steps = A * s + C
+								genSeed = ac.x * genSeed + ac.y;
+							}
+						}
+						n = popc64(__ballot(genValid));  // valid lanes are 0 .. n-1 (only the last group is partial)
+						__syncthreads();
+						if (genValid)
+						{
+							float r1 = pt_rnd(genSeed);
+							float r2 = pt_rnd(genSeed);
+							float jx = a.centreJitter ? 0.5f : r1, jy = a.centreJitter ? 0.5f : r2;
+							float3x o, d;
+							pt_camera_ray(a.cam, a.W, a.H, genPx, genPy, jx, jy, o, d);
+							uint32_t pq = item * PT_WAVE + lane;
+							// payload.seed = seed: the bounce stream starts from the state after the two jitter
+							// draws, while the raygen-local seed continues from the same state for the next sample
+							a.state[pq] = make_float4(1.0f, 1.0f, 1.0f, __uint_as_float(genSeed));
+							a.rad[pq] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+							stage(o, d, 0u, pq);
+						}
+						if (n == 0) continue;
+					}
+					else
+					{
+						// nothing to stage: in the drain, shade a partial batch early so its survivors keep lanes busy
+						if (doneTail != doneHead && popc64(idle) >= 32u)
+						{
+							__syncthreads();
+							flush(doneTail - doneHead);
+							__syncthreads();
+							if (ringCount) continue;
+						}
+						break;
+					}
+					__syncthreads();
+					inCount = n;
+					inPos = 0;
+					raysFetched += n;
+				}
+				uint32_t avail = inCount - inPos, want = popc64(idle);
+				uint32_t n = want < avail ? want : avail;
+				uint32_t rank = popc64(idle & lanesBelow);
+				bool take = (idle & laneBit) && rank < n;
+				if (take)
+				{
+					uint32_t s = inPos + rank;
+					ox = __uint_as_float(sIn[0][s]);
+					oy = __uint_as_float(sIn[1][s]);
+					oz = __uint_as_float(sIn[2][s]);
+					ix = __uint_as_float(sIn[3][s]);
+					iy = __uint_as_float(sIn[4][s]);
+					iz = __uint_as_float(sIn[5][s]);
+					Sx = __uint_as_float(sIn[6][s]);
+					Sy = __uint_as_float(sIn[7][s]);
+					Sz = __uint_as_float(sIn[8][s]);
+					kpack = sIn[9][s];
+					q = sIn[10][s];
+					best.t = tmax;
+					best.prim = PT_NO_HIT;
+					best.V = 0.0f;
+					best.W = 0.0f;
+					best.det = 1.0f;
+					sStack[0][lane] = PT_TRAVERSAL_DONE;  // sentinel: popping an empty stack ends the traversal
+					sp = 1;
+					cur = sc.nNodes ? 0u : PT_TRAVERSAL_DONE;
+				}
+				inPos += n;
+				idle &= ~__ballot(take);
+			}
+			if (!__ballot(q != kNoPath))
+			{
+				// no lane holds a path and nothing could be staged: shade what is parked (its survivors come
+				// back through the ring), or leave when that is empty too
+				if (doneTail != doneHead)
+				{
+					__syncthreads();
+					flush(doneTail - doneHead);
+					__syncthreads();
+					continue;
+				}
+				if (ringCount == 0 && inPos == inCount && genDone) break;
+				continue;
+			}
+		}
+
+		// ------------------------------------------------------------------ B: traverse ----
+		// One step for the LARGER of the two groups (majority-phase stepping, see pt_bounce.hip).
+		const unsigned long long nodeLanes = __ballot(!(cur & PT_LEAF_FLAG));
+		const unsigned long long leafLanes = __ballot((cur & PT_LEAF_FLAG) && cur != PT_TRAVERSAL_DONE);
+		const bool doNode = popc64(nodeLanes) >= popc64(leafLanes);
+		const PtLaneRay ray = { ox, oy, oz, ix, iy, iz, Sx, Sy, Sz, kpack };
+		if (doNode && !(cur & PT_LEAF_FLAG))
+		{
+			if (kStats) ++nodeFetches;
+			pt_node_step<kStackLds>(sc, ray, tmin, best, cur, sp, sStack, lane, mySpill, a.spillStride);
+		}
+		if (!doNode && (cur & PT_LEAF_FLAG) && cur != PT_TRAVERSAL_DONE)
+			pt_leaf_step<kStackLds>(sc, ray, tmin, best, cur, sp, sStack, lane, mySpill, a.spillStride, triTests);
+	}
+
+	if (lane == 0 && raysFetched) a.waveRays[blockIdx.x] += raysFetched;  // one wave per slot: no atomic needed
+	if (kStats)
+	{
+		unsigned long long x = nodeFetches, y = triTests, z = nHits;
+#pragma unroll
+		for (int o = 32; o > 0; o >>= 1)
+		{
+			x += __shfl_xor(x, o);
+			y += __shfl_xor(y, o);
+			z += __shfl_xor(z, o);
+		}
+		if (lane == 0)
+		{
+			atomicAdd(&a.trav[0], x);
+			atomicAdd(&a.trav[1], y);
+			atomicAdd(&a.trav[2], z);
+		}
+	}
+}
+
+// k_accumulate for the item-major radiance layout of k_paths: q(p, i) = ((p / 64) * spp + i) * 64 + p % 64.
+__global__ void __launch_bounds__(256)
+    k_accumulate_items(const float4 *rad, uint32_t WH, uint32_t spp, float4 *image, uint32_t lframe, int mode)
+{
+	uint32_t p = blockIdx.x * 256 + threadIdx.x;
+	if (p >= WH) return;
+	const size_t base = (size_t)(p / PT_WAVE) * spp * PT_WAVE + (p % PT_WAVE);
+	float ax = 0.0f, ay = 0.0f, az = 0.0f;
+	for (uint32_t i = 0; i < spp; ++i)
+	{
+		float4 L = rad[base + (size_t)i * PT_WAVE];
+		ax += L.x;
+		ay += L.y;
+		az += L.z;
+	}
+	float S = (float)spp;
+	float cx = ax / S, cy = ay / S, cz = az / S;
+	float4 out;
+	if (lframe == 0) out = make_float4(cx, cy, cz, 1.0f);
+	else
+	{
+		float4 old = image[p];
+		if (mode == PT_ACCUM_SUM) out = make_float4(old.x + cx, old.y + cy, old.z + cz, 1.0f);
+		else
+		{
+			float al = 1.0f / (float)(lframe + 1);
+			float be = 1.0f - al;
+			out = make_float4(old.x * be + cx * al, old.y * be + cy * al, old.z * be + cz * al, 1.0f);  // mix(old,new,a)
+		}
+	}
+	image[p] = out;
+}
+}  // namespace
+
+void ptLaunchPaths(const PtPathsArgs &args, uint32_t waves, bool stats, hipStream_t s)
+{
+	if (stats) k_paths<true><<<waves, PT_WAVE, 0, s>>>(args);
+	else k_paths<false><<<waves, PT_WAVE, 0, s>>>(args);
+}
+
+void ptLaunchAccumulateItems(const float4 *rad, uint32_t WH, uint32_t spp, float4 *image, uint32_t lframe, int mode,
+                             hipStream_t s)
+{
+	k_accumulate_items<<<(WH + 255) / 256, 256, 0, s>>>(rad, WH, spp, image, lframe, mode);
+}

@@ -51,6 +51,28 @@ void ptLaunchShade(const PtSceneDev &sc, const uint8_t *primEmissive, const uint
 void ptLaunchBounce(const PtSceneDev &sc, const PtQueues &q, int in, PtFrameCounters *fc, int depth, uint32_t denseN,
                     float tmin, float tmax, int lastBounce, const PtLaunchCfg &cfg, unsigned long long *travStats,
                     hipStream_t s);
+// Persistent path kernel (pt_paths.hip): one launch traces every path of the frame from camera ray to
+// termination.  Buffers: ringO/ringD = waves * PT_PATHS_RING records (wave-private survivor rings), state and
+// rad = ceil(W*H/64) * 64 * spp records in item-major order q = ((pixel / 64) * spp + sample) * 64 + pixel % 64.
+#define PT_PATHS_RING 256u
+struct PtPathsArgs
+{
+	PtSceneDev sc;
+	PtCamera cam;
+	uint32_t W, H, spp, seedWord;
+	int centreJitter, maxDepth;
+	float tmin, tmax;
+	const uint2 *lcgSkip;  // [spp]: (A, C) with lcg^(2i)(s) = A * s + C
+	float4 *ringO, *ringD, *state, *rad;
+	uint32_t *itemHead;    // zeroed per frame
+	uint32_t *waveRays;
+	uint32_t *spill;
+	uint32_t spillStride;
+	unsigned long long *trav;  // traversal statistics (stats variant only)
+};
+void ptLaunchPaths(const PtPathsArgs &args, uint32_t waves, bool stats, hipStream_t s);
+void ptLaunchAccumulateItems(const float4 *rad, uint32_t WH, uint32_t spp, float4 *image, uint32_t lframe, int mode,
+                             hipStream_t s);
 void ptLaunchAccumulate(const PtQueues &q, uint32_t WH, uint32_t spp, float4 *image, uint32_t lframe, int mode,
                         hipStream_t s);
 void ptLaunchDebugRng(uint32_t n, const uint32_t *v0, const uint32_t *v1, uint32_t nSteps, uint32_t *outTea,

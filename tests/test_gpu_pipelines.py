@@ -1,0 +1,112 @@
+"""GPU: the three execution pipelines of pt_render_frame (persistent path kernel, one fused kernel per
+bounce, split extend/shade) are three implementations of one specification: each must reproduce the
+oracle's image and ray count bit for bit."""
+import os
+
+import numpy as np
+import pytest
+
+from conftest import GOLDEN, bits
+
+pytestmark = pytest.mark.gpu
+KAT = np.load(os.path.join(GOLDEN, "oracle_kat.npz"))
+PIPELINES = {"fused": 0, "split": 1, "persistent": 2}
+
+
+@pytest.mark.parametrize("pipeline", list(PIPELINES))
+def test_golden_small_image_every_pipeline(rt, pa, cornell, pipeline):
+    W, H = 64, 48
+    view, proj = pa.reference_camera(W, H)
+    rt.setPipeline(PIPELINES[pipeline])
+    rt.buildBlas(cornell)
+    rt.resize(W, H)
+    rt.setCamera(view, proj)
+    rt.setParams(spp_per_frame=4, max_depth=8, seed=0)
+    rt.raytrace(3)
+    assert np.array_equal(bits(rt.readImage()), bits(KAT["cornell_image_64x48_f3_s4_d8"]))
+    assert rt.stats().rays_total == int(KAT["cornell_image_rays"][0])
+    rt.setParams(spp_per_frame=10, max_depth=20, seed=7)  # the reference's own constants
+    rt.resetFrame()
+    rt.raytrace(2)
+    assert np.array_equal(bits(rt.readImage()), bits(KAT["cornell_image_64x48_f2_s10_d20_seed7"]))
+
+
+@pytest.mark.parametrize("pipeline", list(PIPELINES))
+@pytest.mark.parametrize("W,H,spp,depth", [(1, 1, 1, 1), (7, 5, 3, 2), (257, 3, 2, 8), (63, 65, 5, 20), (130, 2, 17, 3),
+                                            (640, 360, 16, 8)])
+def test_ragged_extents_every_pipeline(rt, pa, cornell, ocornell, pipeline, W, H, spp, depth):
+    """Partial pixel groups (W*H not a multiple of 64), more samples than a claim holds, depth 1 and 20."""
+    view, proj = pa.reference_camera(W, H)
+    rt.setPipeline(PIPELINES[pipeline])
+    rt.buildBlas(cornell)
+    rt.resize(W, H)
+    rt.setCamera(view, proj)
+    rt.setParams(spp_per_frame=spp, max_depth=depth, seed=9)
+    frames = 3 if W * H < 100000 else 2
+    rt.raytrace(frames)
+    want, rays = ocornell.render(view, proj, W, H, frames=frames, spp_per_frame=spp, max_depth=depth, seed=9)
+    assert rt.stats().rays_total == rays
+    assert np.array_equal(bits(rt.readImage()), bits(want))
+
+
+@pytest.mark.parametrize("pipeline", list(PIPELINES))
+def test_emission_that_does_not_terminate(rt, pa, O, cornell, pipeline):
+    """rchit:56 terminates a path only when Ke.x+Ke.y+Ke.z > 0, while rgen:78 adds emission whenever a
+    component is non-zero: with Ke = (2, -2, 0) on the walls a path collects emission at several bounces."""
+    mats = cornell.materials.copy()
+    for m in range(len(mats)):
+        if not np.any(mats[m, 3:6]):
+            mats[m, 3:6] = (2.0, -2.0, 0.0) if m % 2 else (0.0, 0.5, -0.5)
+    sc = pa.Scene(cornell.vertices, cornell.indices, mats, cornell.mat_indices)
+    osc = O.OracleScene(sc.vertices, sc.indices, sc.materials, sc.mat_indices)
+    W, H = 96, 64
+    view, proj = pa.reference_camera(W, H)
+    rt.setPipeline(PIPELINES[pipeline])
+    rt.buildBlas(sc)
+    rt.resize(W, H)
+    rt.setCamera(view, proj)
+    rt.setParams(spp_per_frame=5, max_depth=6, seed=3)
+    rt.raytrace(2)
+    want, rays = osc.render(view, proj, W, H, frames=2, spp_per_frame=5, max_depth=6, seed=3)
+    assert rt.stats().rays_total == rays
+    assert np.array_equal(bits(rt.readImage()), bits(want))
+    assert (want[..., 1] < 0).any()  # negative emission really was collected
+
+
+@pytest.mark.parametrize("pipeline", list(PIPELINES))
+def test_mesh_scene_every_pipeline(rt, pa, O, pipeline):
+    """A scene with a deeper tree than Cornell (4.5k triangles, open to the sky: most paths end in a miss)."""
+    sc = pa.scenes.grid_mesh(48, 47)
+    osc = O.OracleScene(sc.vertices, sc.indices, sc.materials, sc.mat_indices)
+    W, H = 160, 90
+    view, proj = pa.reference_camera(W, H)
+    rt.setPipeline(PIPELINES[pipeline])
+    rt.buildBlas(sc)
+    rt.resize(W, H)
+    rt.setCamera(view, proj)
+    rt.setParams(spp_per_frame=3, max_depth=5, seed=1)
+    rt.raytrace(2)
+    want, rays = osc.render(view, proj, W, H, frames=2, spp_per_frame=3, max_depth=5, seed=1)
+    assert rt.stats().rays_total == rays
+    assert np.array_equal(bits(rt.readImage()), bits(want))
+
+
+def test_pipelines_agree_at_full_size(rt, pa, cornell):
+    """BASELINE.json configs[1] extent (1920x1080, 16 spp, depth 8): too slow for the oracle, so the three
+    pipelines check each other -- whole image and ray count, bit for bit, frames 0 and 1."""
+    W, H = 1920, 1080
+    view, proj = pa.reference_camera(W, H)
+    rt.buildBlas(cornell)
+    rt.resize(W, H)
+    rt.setCamera(view, proj)
+    rt.setParams(spp_per_frame=16, max_depth=8, seed=0)
+    out = {}
+    for name, mode in PIPELINES.items():
+        rt.setPipeline(mode)
+        rt.resetFrame()
+        rt.resetStats()
+        rt.raytrace(2)
+        out[name] = (rt.readImage().copy(), rt.stats().rays_total)
+    for name in ("split", "persistent"):
+        assert out[name][1] == out["fused"][1]
+        assert np.array_equal(bits(out[name][0]), bits(out["fused"][0])), name
