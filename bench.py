@@ -45,7 +45,7 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample-frames", type=int, default=1)
     ap.add_argument("--out-image", default="")
-    ap.add_argument("--pipeline", choices=["persistent", "fused", "split"], default="fused")
+    ap.add_argument("--pipeline", choices=["persistent", "fused", "split"], default="persistent")
     ap.add_argument("--builder", choices=["ploc", "lbvh"], default="ploc", help="BVH2 construction before the BVH4 collapse")
     ap.add_argument("--force-dist", action="store_true", help="initialise torch.distributed/RCCL even for one rank (rehearses the N>1 path on one GPU)")
     return ap.parse_args()
@@ -168,7 +168,13 @@ def main():
         scene_bytes = st.bvh_nodes * 64.0 + 3 * st.bvh_tris * 48.0
         paths_total = float(W) * H * S * a.steps
         p_alive = max(0.0, (rays_local - paths_total) / max(1.0, rays_local))  # rays of bounce >= 1 = survivors
-        if a.pipeline == "fused":
+        p_prim = paths_total / max(1.0, rays_local)
+        if a.pipeline == "persistent":
+            # k_paths: a new path writes its 16 B state record and zeroes its 16 B radiance record; a hit reads
+            # the state record; a survivor writes it back and makes one round trip (32 B out, 32 B in) through
+            # the wave's ring.  Camera rays never exist in memory.
+            bytes_per_ray_extend = 32.0 * p_prim + 16.0 * p_hit + 80.0 * p_alive
+        elif a.pipeline == "fused":
             bytes_per_ray_extend = 32.0 + 16.0 * p_hit + 48.0 * p_alive
         else:
             bytes_per_ray_extend = 48.0
@@ -179,7 +185,7 @@ def main():
         rays_per_launch = rays_local / max(1, st.extend_launches)
         achieved = (rays_per_launch * bytes_per_ray_extend + scene_bytes) / (ext_ms * 1e-3) / 1e9 if ext_ms > 0 else 0.0
         traffic = None
-        tpath = os.path.join(ROOT, "profiles", "traffic_bounce.json" if a.pipeline == "fused" else "traffic_extend.json")
+        tpath = os.path.join(ROOT, "profiles", {"persistent": "traffic_paths.json", "fused": "traffic_bounce.json"}.get(a.pipeline, "traffic_extend.json"))
         if os.path.exists(tpath):
             try:
                 with open(tpath) as f:
@@ -198,7 +204,7 @@ def main():
             "rays_per_step_per_gpu": rays_local / a.steps,
             "roofline": {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
-                         "kernel": "k_bounce" if a.pipeline == "fused" else "k_extend", "p_alive": round(p_alive, 4),
+                         "kernel": {"persistent": "k_paths", "fused": "k_bounce"}.get(a.pipeline, "k_extend"), "p_alive": round(p_alive, 4),
                          "launch_ms": round(ext_ms, 4), "rays_per_launch": rays_per_launch,
                          "bytes_per_ray": round(bytes_per_ray_extend, 2),
                          "cache_served_bytes_per_ray": round(cache_bytes_per_ray, 2),
@@ -207,12 +213,15 @@ def main():
                          "extend_mrays_per_s": round(rays_per_launch / (ext_ms * 1e-3) / 1e6, 1) if ext_ms > 0 else 0.0,
                          "nodes_per_ray": round(nodes_per_ray, 3),
                          "tris_per_ray": round(tris_per_ray, 3), "p_hit": round(p_hit, 4)},
-            "roofline_step": {"bytes_per_ray": round(bytes_per_ray_step, 2),
+            "roofline_step": {"note": "SURVEY.md 8(d) whole-step formula; its traversal/gather terms are L1/L2 traffic on this "
+                                      "2.5 KB scene, so frac may exceed 1 -- HBM-only accounting is `roofline`",
+                              "bytes_per_ray": round(bytes_per_ray_step, 2),
                               "achieved": round(mrays / world * 1e6 * bytes_per_ray_step / 1e9, 2), "unit": "GB/s",
                               "frac": round(mrays / world * 1e6 * bytes_per_ray_step / 1e9 / HBM_PEAK_GBS, 5),
                               "queue_only_frac": round(mrays / world * 1e6 * 160.0 / 1e9 / HBM_PEAK_GBS, 5)},
-            "kernel_ms": {("bounce_mean" if a.pipeline == "fused" else "extend_mean"): round(ext_ms, 4),
-                          "shade_mean": round(st.shade_ms_total / max(1, st.shade_launches), 4)},
+            "kernel_ms": {{"persistent": "paths_mean", "fused": "bounce_mean"}.get(a.pipeline, "extend_mean"): round(ext_ms, 4),
+                          ("accumulate_mean" if a.pipeline == "persistent" else "shade_mean"):
+                          round(st.shade_ms_total / max(1, st.shade_launches), 4)},
             "pipeline": a.pipeline, "builder": a.builder,
             "bvh": {"nodes": st.bvh_nodes, "depth": st.bvh_depth, "tris": st.bvh_tris, "build_ms": round(st.build_ms, 3)},
         }

@@ -144,8 +144,9 @@ int pt_set_frame_schedule(pt_ctx *ctx, uint32_t first, uint32_t stride);
 int pt_set_accum_mode(pt_ctx *ctx, int mode);
 
 /* How one dispatch is executed on the device (no reference counterpart; results are bit-identical):
- * FUSED (default) = one persistent kernel per bounce (traverse + shade + compact, lanes refilled in
- * flight); SPLIT = the classic wavefront pair k_extend / k_shade with the hit records in HBM. */
+ * PERSISTENT (default) = one kernel per frame; FUSED = one persistent kernel per bounce (traverse + shade +
+ * compact, lanes refilled in flight); SPLIT = the classic wavefront pair k_extend / k_shade with the hit
+ * records in HBM.  PT_ACCEL_BRUTE_FORCE always runs on SPLIT. */
 #define PT_PIPELINE_FUSED 0
 #define PT_PIPELINE_SPLIT 1
 #define PT_PIPELINE_PERSISTENT 2 /* one persistent kernel per FRAME: waves generate camera rays, keep their paths

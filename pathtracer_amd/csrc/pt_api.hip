@@ -51,7 +51,7 @@ struct pt_ctx
 	uint32_t seed = 0;
 	uint32_t firstFrame = 0, frameStride = 1;
 	int accumMode = PT_ACCUM_MEAN;
-	int pipeline = PT_PIPELINE_FUSED;
+	int pipeline = PT_PIPELINE_PERSISTENT;
 	int frame = -1;  // m_pcRay.frame
 	bool haveCamera = false;
 	PtCamera cam;

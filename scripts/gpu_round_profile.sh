@@ -18,4 +18,4 @@ timeout -s KILL 90 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_fe
 timeout -s KILL 90 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/pmc_write -- python3 $R/bench.py --steps 4 --warmup 1 --no-cpu-baseline > $OUT/pmc_write.log 2>&1 || { tail $OUT/pmc_write.log; exit 1; }
 cd $R
 python scripts/pmc_summary.py $OUT/pmc_fetch; python scripts/pmc_summary.py $OUT/pmc_write
-find $OUT/stats -name "*kernel_stats.csv" | head -1 | xargs cat | cut -c1-200
+find $OUT/stats -name "*kernel_stats.csv" | head -1 | xargs cat | cut -c1-120
