@@ -120,6 +120,13 @@ def main():
     nodes_per_ray = ts.trav_nodes / rays_stat
     tris_per_ray = ts.trav_tris / rays_stat
     p_hit = ts.trav_hits / rays_stat
+    divergence = None
+    if ts.trav_node_steps and ts.trav_leaf_steps:
+        divergence = {"node_step_lane_util": round(ts.trav_nodes / (64.0 * ts.trav_node_steps), 4),
+                      "leaf_step_lane_util": round(ts.trav_leaf_visits / (64.0 * ts.trav_leaf_steps), 4),
+                      "node_steps_per_64_rays": round(64.0 * ts.trav_node_steps / rays_stat, 3),
+                      "leaf_steps_per_64_rays": round(64.0 * ts.trav_leaf_steps / rays_stat, 3),
+                      "leaf_visits_per_ray": round(ts.trav_leaf_visits / rays_stat, 3)}
     rt.setProfiling(0)
 
     # ---- warmup ----
@@ -222,7 +229,7 @@ def main():
             "kernel_ms": {{"persistent": "paths_mean", "fused": "bounce_mean"}.get(a.pipeline, "extend_mean"): round(ext_ms, 4),
                           ("accumulate_mean" if a.pipeline == "persistent" else "shade_mean"):
                           round(st.shade_ms_total / max(1, st.shade_launches), 4)},
-            "pipeline": a.pipeline, "builder": a.builder,
+            "pipeline": a.pipeline, "builder": a.builder, "divergence": divergence,
             "bvh": {"nodes": st.bvh_nodes, "depth": st.bvh_depth, "tris": st.bvh_tris, "build_ms": round(st.build_ms, 3)},
         }
         if world == 1 and not a.no_cpu_baseline:

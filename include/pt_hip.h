@@ -76,6 +76,9 @@ typedef struct PtStats
 	uint64_t trav_nodes;        /* wide nodes fetched */
 	uint64_t trav_tris;         /* ray/triangle tests */
 	uint64_t trav_hits;         /* rays that found a hit */
+	uint64_t trav_leaf_visits;  /* leaves entered (lane level) */
+	uint64_t trav_node_steps;   /* wave-level node steps: trav_nodes / (64 * trav_node_steps) = lane utilisation */
+	uint64_t trav_leaf_steps;   /* wave-level leaf steps (persistent pipeline only, like the two above) */
 } PtStats;
 
 typedef struct pt_ctx pt_ctx;

@@ -18,8 +18,8 @@ from ._lib import (PT_ACCEL_BRUTE_FORCE, PT_ACCEL_BVH4, PT_ACCEL_BVH4_PLOC, PT_A
                    PT_PROFILE_TRAVERSAL, PT_PIPELINE_FUSED, PT_PIPELINE_SPLIT, PT_PIPELINE_PERSISTENT, PtStats)
 
 HIT_DTYPE = np.dtype([("t", np.float32), ("u", np.float32), ("v", np.float32), ("prim", np.uint32)])
-NODE_DTYPE = np.dtype([("origin", np.float32, 3), ("exps", np.uint32), ("child", np.uint32, 4),
-                       ("qlo", np.uint8, (3, 4)), ("qhi", np.uint8, (3, 4)), ("pad", np.uint32, 2)])
+NODE_DTYPE = np.dtype([("origin", np.float32, 3), ("scale_x", np.float32), ("child", np.uint32, 4),
+                       ("qlo", np.uint8, (3, 4)), ("qhi", np.uint8, (3, 4)), ("scale_yz", np.float32, 2)])
 TRI_DTYPE = np.dtype([("v0", np.float32, 3), ("v1", np.float32, 3), ("v2", np.float32, 3), ("prim", np.uint32),
                       ("pad", np.uint32, 2)])
 assert HIT_DTYPE.itemsize == 16 and NODE_DTYPE.itemsize == 64 and TRI_DTYPE.itemsize == 48

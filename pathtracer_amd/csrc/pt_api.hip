@@ -60,7 +60,7 @@ struct pt_ctx
 	size_t queueCap = 0;  // records
 	float4 *image = nullptr;
 	PtFrameCounters *counters = nullptr;
-	unsigned long long *dStats = nullptr;  // [0] rays_total [1] rays_last_frame [2..4] traversal counters
+	unsigned long long *dStats = nullptr;  // [0] rays_total [1] rays_last_frame [2..7] traversal counters
 	PtLaunchCfg cfg = {};
 	uint2 *dLcgSkip = nullptr;  // persistent pipeline: LCG skip-ahead pairs for 0, 2, 4, .. steps
 	int lcgSkipSpp = 0;
@@ -259,8 +259,8 @@ extern "C" pt_ctx *pt_create(int device)
 	bool ok = hipStreamCreateWithFlags(&c->ownStream, hipStreamNonBlocking) == hipSuccess;
 	c->stream = c->ownStream;
 	ok = ok && hipMalloc(&c->counters, sizeof(PtFrameCounters)) == hipSuccess;
-	ok = ok && hipMalloc(&c->dStats, 5 * sizeof(unsigned long long)) == hipSuccess;
-	ok = ok && hipMemset(c->dStats, 0, 5 * sizeof(unsigned long long)) == hipSuccess;
+	ok = ok && hipMalloc(&c->dStats, 8 * sizeof(unsigned long long)) == hipSuccess;
+	ok = ok && hipMemset(c->dStats, 0, 8 * sizeof(unsigned long long)) == hipSuccess;
 	// persistent grid: blocks of 256 threads per CU (tuning knob PT_BLOCKS_PER_CU, default 4)
 	int blocksPerCU = 4;
 	if (const char *e = getenv("PT_BLOCKS_PER_CU"))
@@ -673,7 +673,7 @@ extern "C" int pt_get_stats(pt_ctx *c, PtStats *out)
 {
 	if (!c || !out) return fail(c, PT_EINVAL, "pt_get_stats: null argument");
 	PT_HIP(c, hipSetDevice(c->device));
-	unsigned long long h[5] = { 0, 0, 0, 0, 0 };
+	unsigned long long h[8] = { 0, 0, 0, 0, 0, 0, 0, 0 };
 	PT_HIP(c, hipMemcpyAsync(h, c->dStats, sizeof(h), hipMemcpyDeviceToHost, c->stream));
 	PT_HIP(c, hipStreamSynchronize(c->stream));
 	drainEvents(c);
@@ -693,6 +693,9 @@ extern "C" int pt_get_stats(pt_ctx *c, PtStats *out)
 	out->trav_nodes = h[2];
 	out->trav_tris = h[3];
 	out->trav_hits = h[4];
+	out->trav_leaf_visits = h[5];
+	out->trav_node_steps = h[6];
+	out->trav_leaf_steps = h[7];
 	return PT_OK;
 }
 
@@ -701,7 +704,7 @@ extern "C" int pt_reset_stats(pt_ctx *c)
 	if (!c) return fail(nullptr, PT_EINVAL, "null context");
 	PT_HIP(c, hipStreamSynchronize(c->stream));
 	drainEvents(c);
-	PT_HIP(c, hipMemset(c->dStats, 0, 5 * sizeof(unsigned long long)));
+	PT_HIP(c, hipMemset(c->dStats, 0, 8 * sizeof(unsigned long long)));
 	c->extendMs = c->shadeMs = 0.0;
 	c->extendLaunches = c->shadeLaunches = c->framesRendered = 0;
 	return PT_OK;

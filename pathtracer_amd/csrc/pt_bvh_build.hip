@@ -454,8 +454,9 @@ __global__ void __launch_bounds__(kBlock)
 	node.origin[0] = org[0];
 	node.origin[1] = org[1];
 	node.origin[2] = org[2];
-	node.exps = expBits[0] | (expBits[1] << 8) | (expBits[2] << 16);
-	node.pad[0] = node.pad[1] = 0;
+	node.scaleX = scale[0];
+	node.scaleY = scale[1];
+	node.scaleZ = scale[2];
 	for (int a = 0; a < 3; ++a)
 	{
 		node.qlo[a] = 0xFFFFFFFFu;  // empty slots: lo = 255, hi = 0
@@ -740,7 +741,6 @@ hipError_t ptBuildBvh4(const PtBuildInput &in, PtBuildOutput &out, hipStream_t s
 	PtNode4 *nodes = nullptr;
 	PtTri48 *tris = nullptr;
 	uint32_t *codes = nullptr, *order = nullptr;
-	float *cbounds = nullptr;
 	TRY(hipMalloc(&nodes, sizeof(PtNode4) * (size_t)n));  // a wide node has >= 2 children unless it is the root
 	TRY(hipMalloc(&tris, 3 * sizeof(PtTri48) * (size_t)n));  // three axis-rotated planes
 	TRY(hipMalloc(&codes, 4 * (size_t)n));

@@ -234,18 +234,19 @@ __device__ __forceinline__ PtHit pt_finish_hit(const PtBest &b, float tmax)
 
 // ------------------------------------------------------------------ wide BVH layout ----
 // 64-byte quantised BVH4 node: one 64 B-aligned record = four 16-byte loads per lane.
-//   child box c, axis a:  lo = origin[a] + qlo[a][c] * 2^(exp[a]-127),  hi likewise with qhi.
+//   child box c, axis a:  lo = origin[a] + qlo[a][c] * scale[a],  hi likewise with qhi; scale[a] is a power of two
+//   stored as a float (no decode instructions in the traversal).
 //   An empty child slot has qlo = 255, qhi = 0 on every axis (never intersected).
 //   child[c]: bit 31 = leaf.  inner: node index.  leaf: bits 30..28 = triangle count - 1,
 //   bits 27..0 = first triangle in the leaf-ordered triangle array.
 struct __attribute__((aligned(64))) PtNode4
 {
 	float origin[3];
-	uint32_t exps;       // exp_x | exp_y << 8 | exp_z << 16 (biased exponents of the power-of-two scales)
+	float scaleX;        // power-of-two quantisation step per axis (x here, y and z at the end of the record)
 	uint32_t child[4];
 	uint32_t qlo[3];     // qlo[a] = 4 bytes, one per child
 	uint32_t qhi[3];
-	uint32_t pad[2];
+	float scaleY, scaleZ;
 };
 static_assert(sizeof(PtNode4) == 64, "PtNode4 must be 64 bytes");
 

@@ -5,7 +5,7 @@
 // of >= 256 rays ~ 60 us apart: measured ~80 us fixed cost per launch, 10 % of the frame), k_generate is a
 // separate HBM-bound pass (6 %), and all survivors make a round trip through global chunked queues.  Here
 //   * a wave generates its primary rays itself, 64 at a time at full lane utilisation (the staging phase
-//     of k_bounce), from work items claimed with one atomic per up to 16 items;
+//     of k_bounce), from work items claimed with one atomic per up to 8 items;
 //   * lanes whose traversal ended are refilled inside the wave, finished hits are parked in an LDS ring
 //     and shaded 64 at a time (both exactly as in k_bounce);
 //   * survivors of the shading go to a small WAVE-PRIVATE ring in global memory (256 records, no atomics,
@@ -29,10 +29,10 @@
 #define PT_PATHS_MIN_ITEMS 2u
 #endif
 #ifndef PT_PATHS_MAX_ITEMS
-#define PT_PATHS_MAX_ITEMS 16u
+#define PT_PATHS_MAX_ITEMS 8u
 #endif
 #ifndef PT_REFILL_LANES
-#define PT_REFILL_LANES 16
+#define PT_REFILL_LANES 32
 #endif
 
 namespace
@@ -78,7 +78,7 @@ __global__ void __launch_bounds__(PT_WAVE) k_paths(PtPathsArgs a)
 	uint32_t inCount = 0, inPos = 0;      // prepared rays in sIn
 	uint32_t doneHead = 0, doneTail = 0;  // LDS ring of finished rays
 	uint32_t raysFetched = 0;
-	uint32_t nodeFetches = 0, triTests = 0, nHits = 0;
+	uint32_t nodeFetches = 0, triTests = 0, nHits = 0, leafVisits = 0, nodeSteps = 0, leafSteps = 0;
 
 	// per-lane ray state
 	float ox = 0, oy = 0, oz = 0, ix = 0, iy = 0, iz = 0, Sx = 0, Sy = 0, Sz = 0;
@@ -342,31 +342,43 @@ __global__ void __launch_bounds__(PT_WAVE) k_paths(PtPathsArgs a)
 		const unsigned long long leafLanes = __ballot((cur & PT_LEAF_FLAG) && cur != PT_TRAVERSAL_DONE);
 		const bool doNode = popc64(nodeLanes) >= popc64(leafLanes);
 		const PtLaneRay ray = { ox, oy, oz, ix, iy, iz, Sx, Sy, Sz, kpack };
+		if (kStats)
+		{
+			if (doNode) ++nodeSteps;  // wave-uniform
+			else ++leafSteps;
+		}
 		if (doNode && !(cur & PT_LEAF_FLAG))
 		{
 			if (kStats) ++nodeFetches;
 			pt_node_step<kStackLds>(sc, ray, tmin, best, cur, sp, sStack, lane, mySpill, a.spillStride);
 		}
 		if (!doNode && (cur & PT_LEAF_FLAG) && cur != PT_TRAVERSAL_DONE)
+		{
+			if (kStats && cur != PT_EMPTY_CHILD) ++leafVisits;
 			pt_leaf_step<kStackLds>(sc, ray, tmin, best, cur, sp, sStack, lane, mySpill, a.spillStride, triTests);
+		}
 	}
 
 	if (lane == 0 && raysFetched) a.waveRays[blockIdx.x] += raysFetched;  // one wave per slot: no atomic needed
 	if (kStats)
 	{
-		unsigned long long x = nodeFetches, y = triTests, z = nHits;
+		unsigned long long x = nodeFetches, y = triTests, z = nHits, w = leafVisits;
 #pragma unroll
 		for (int o = 32; o > 0; o >>= 1)
 		{
 			x += __shfl_xor(x, o);
 			y += __shfl_xor(y, o);
 			z += __shfl_xor(z, o);
+			w += __shfl_xor(w, o);
 		}
 		if (lane == 0)
 		{
 			atomicAdd(&a.trav[0], x);
 			atomicAdd(&a.trav[1], y);
 			atomicAdd(&a.trav[2], z);
+			atomicAdd(&a.trav[3], w);
+			atomicAdd(&a.trav[4], (unsigned long long)nodeSteps);
+			atomicAdd(&a.trav[5], (unsigned long long)leafSteps);
 		}
 	}
 }

@@ -66,8 +66,7 @@ __device__ __forceinline__ PtHit traverseBvh4(const PtSceneDev &sc, float3x o, f
 			if (kStats) ++nodeFetches;
 			const uint4 *np = reinterpret_cast<const uint4 *>(sc.nodes + cur);
 			uint4 n0 = np[0], n1 = np[1], n2 = np[2], n3 = np[3];
-			float sx = __uint_as_float((n0.w & 0xFFu) << 23), sy = __uint_as_float(((n0.w >> 8) & 0xFFu) << 23),
-			      sz = __uint_as_float(((n0.w >> 16) & 0xFFu) << 23);
+			float sx = __uint_as_float(n0.w), sy = __uint_as_float(n3.z), sz = __uint_as_float(n3.w);
 			float ax = sx * inv.x, ay = sy * inv.y, az = sz * inv.z;
 			float bx = (__uint_as_float(n0.x) - o.x) * inv.x, by = (__uint_as_float(n0.y) - o.y) * inv.y,
 			      bz = (__uint_as_float(n0.z) - o.z) * inv.z;

@@ -60,13 +60,12 @@ __device__ __forceinline__ void pt_node_step(const PtSceneDev &sc, const PtLaneR
 	// the entry that is popped if no child is hit; read early so its latency hides under the box tests
 	const bool fastStack = sp <= kStackLds - 3;
 	uint32_t top = sStack[sp - 1 < kStackLds ? sp - 1 : 0][lane];
-	float sx = __uint_as_float((n0.w & 0xFFu) << 23), sy = __uint_as_float(((n0.w >> 8) & 0xFFu) << 23),
-	      sz = __uint_as_float(((n0.w >> 16) & 0xFFu) << 23);
+	float sx = __uint_as_float(n0.w), sy = __uint_as_float(n3.z), sz = __uint_as_float(n3.w);
 	float ax = sx * ix, ay = sy * iy, az = sz * iz;
 	float bx = (__uint_as_float(n0.x) - ox) * ix, by = (__uint_as_float(n0.y) - oy) * iy,
 	      bz = (__uint_as_float(n0.z) - oz) * iz;
 	const bool negx = kpack & 64u, negy = kpack & 128u, negz = kpack & 256u;
-	// n2 = qlo[0..2], qhi[0]; n3 = qhi[1..2], pad
+	// n2 = qlo[0..2], qhi[0]; n3 = qhi[1..2], scaleY, scaleZ
 	uint32_t nqx = negx ? n2.w : n2.x, fqx = negx ? n2.x : n2.w;
 	uint32_t nqy = negy ? n3.x : n2.y, fqy = negy ? n2.y : n3.x;
 	uint32_t nqz = negz ? n3.y : n2.z, fqz = negz ? n2.z : n3.y;
@@ -99,7 +98,12 @@ __device__ __forceinline__ void pt_node_step(const PtSceneDev &sc, const PtLaneR
 		ref[a] = rl_;                         \
 		ref[b] = rh_;                         \
 	}
+#ifndef PT_SORT_FULL
+	// nearest child to slot 0 only; the pending ones are pushed in slot order (exact when <= 2 children are hit)
+	PT_CE(0, 1) PT_CE(2, 3) PT_CE(0, 2)
+#else
 	PT_CE(0, 1) PT_CE(2, 3) PT_CE(0, 2) PT_CE(1, 3) PT_CE(1, 2)
+#endif
 #undef PT_CE
 	const bool h0 = tn[0] < INFINITY, h1 = tn[1] < INFINITY, h2 = tn[2] < INFINITY, h3 = tn[3] < INFINITY;
 	if (fastStack)

@@ -6,7 +6,7 @@ sc = pa.scenes.cornell_box()
 rt = pa.HipRaytracing(0); rt.buildBlas(sc)
 nodes, tris = rt.debugReadBvh()
 for i, nd in enumerate(nodes):
-    scale = np.array([np.uint32(((int(nd["exps"]) >> (8 * a)) & 0xFF) << 23) for a in range(3)], dtype=np.uint32).view(np.float32)
+    scale = np.array([nd["scale_x"], nd["scale_yz"][0], nd["scale_yz"][1]], dtype=np.float32)
     print("node", i, "origin", nd["origin"])
     for c in range(4):
         ref = int(nd["child"][c])

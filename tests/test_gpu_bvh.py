@@ -38,8 +38,7 @@ def validate_bvh(nodes, tris, scene):
         depth_max = max(depth_max, depth)
         seen_nodes[ni] += 1
         nd = nodes[ni]
-        scale = np.array([np.uint32(((int(nd["exps"]) >> (8 * a)) & 0xFF) << 23) for a in range(3)],
-                         dtype=np.uint32).view(np.float32).astype(np.float64)
+        scale = np.array([nd["scale_x"], nd["scale_yz"][0], nd["scale_yz"][1]], dtype=np.float32).astype(np.float64)
         org = nd["origin"].astype(np.float64)
         for c in range(4):
             ref = int(nd["child"][c])
