@@ -142,6 +142,15 @@ int pt_set_params(pt_ctx *ctx, int spp_per_frame, int max_depth, float tmin, flo
  * the frame-0 pixel-centre rule use the global index).  Default first=0, stride=1. */
 int pt_set_frame_schedule(pt_ctx *ctx, uint32_t first, uint32_t stride);
 
+/* Current extent of the accumulation image (0 x 0 before pt_resize; pt_load_checkpoint may change it). */
+int pt_image_extent(pt_ctx *ctx, uint32_t *width, uint32_t *height);
+
+/* Image-tile split: restrict pt_render_frame to the w x h rectangle at (x0, y0);
+ * pixels outside keep their value (0 after pt_resize), so per-GPU tiles combine with the same sum-reduce as
+ * sample streams.  Every pixel's value is independent of the tiling (seeds use the full-image pixel index).
+ * w = h = 0 restores the whole image; pt_resize does too. */
+int pt_set_tile(pt_ctx *ctx, uint32_t x0, uint32_t y0, uint32_t w, uint32_t h);
+
 #define PT_ACCUM_MEAN 0  /* running mean, mix(old,new,1/(frame+1)): raytrace.rgen:88-95 */
 #define PT_ACCUM_SUM 1   /* raw per-frame sums (exact, order-independent multi-GPU reduce) */
 int pt_set_accum_mode(pt_ctx *ctx, int mode);
@@ -174,6 +183,14 @@ int pt_read_image(pt_ctx *ctx, float *rgba32f);
 int pt_image_device_ptr(pt_ctx *ctx, void **dev_ptr);
 /* Overwrites the accumulation image from device memory (e.g. a reduced multi-GPU result). */
 int pt_write_image_from_device(pt_ctx *ctx, const void *dev_rgba32f);
+
+/* Accumulation checkpoint: the RGBA32F image plus everything the frame counter's meaning depends on (frame
+ * index, extent, sampling parameters, seed, frame schedule, accumulation mode).  The reference keeps this
+ * state only on the GPU and loses it on exit or resize (VulkanRaytracing.cpp:904-913, main.cpp:435).  Load
+ * into a context whose scene, acceleration structure and camera are set: the next pt_render_frame continues
+ * with frame + 1 and the final image is bit-identical to an uninterrupted run. */
+int pt_save_checkpoint(pt_ctx *ctx, const char *path);
+int pt_load_checkpoint(pt_ctx *ctx, const char *path);
 
 /* post.frag + the B8G8R8A8_SRGB attachment (VulkanSwapchain.cpp:8): linear RGBA32F -> 8-bit
  * sRGB RGBA, W*H*4 bytes.  Synchronises. */
@@ -230,6 +247,9 @@ void pt_reference_camera(uint32_t width, uint32_t height, float view[16], float 
 /* Writers for the accumulation image (the reference only presents to a window). */
 int pt_write_pfm(const char *path, const float *rgba32f, uint32_t width, uint32_t height);
 int pt_write_ppm(const char *path, const uint8_t *rgba8, uint32_t width, uint32_t height);
+/* 8-bit RGBA PNG (stored deflate blocks, sRGB chunk) of what the sRGB swapchain would show
+ * (VulkanSwapchain.cpp:8, shaders/post.frag:9-13): feed it pt_read_image_srgb8's output. */
+int pt_write_png(const char *path, const uint8_t *rgba8, uint32_t width, uint32_t height);
 
 #ifdef __cplusplus
 }

@@ -9,6 +9,7 @@ libpt_hip.so.  No function in this module has a CPU fallback.
 from __future__ import annotations
 
 import ctypes as C
+import os
 from dataclasses import dataclass
 
 import numpy as np
@@ -100,6 +101,28 @@ def inverse4(m):
     return out
 
 
+def _write_image(fn, path, img, dtype):
+    a = np.ascontiguousarray(img, dtype=dtype)
+    if a.ndim != 3 or a.shape[2] != 4:
+        raise ValueError("image must be (H, W, 4)")
+    rc = fn(os.fsencode(path), _p(a), a.shape[1], a.shape[0])
+    if rc:
+        raise PathTracerError(rc, _lib.lib().pt_last_error(None).decode())
+
+
+def write_png(path, rgba8):
+    """8-bit RGBA PNG of `HipRaytracing.readImageSrgb8()` (pt_write_png)."""
+    _write_image(_lib.lib().pt_write_png, path, rgba8, np.uint8)
+
+
+def write_ppm(path, rgba8):
+    _write_image(_lib.lib().pt_write_ppm, path, rgba8, np.uint8)
+
+
+def write_pfm(path, rgba32f):
+    _write_image(_lib.lib().pt_write_pfm, path, rgba32f, np.float32)
+
+
 def reference_camera(width, height):
     """view, proj of main.cpp:1465-1480 (column-major float[16] each)."""
     v = np.zeros(16, dtype=np.float32)
@@ -186,6 +209,10 @@ class HipRaytracing:
     def setFrameSchedule(self, first=0, stride=1):
         self._check(self._L.pt_set_frame_schedule(self._ctx, first, stride))
 
+    def setTile(self, x0=0, y0=0, w=0, h=0):
+        """Restrict dispatches to a sub-rectangle (image-tile split); w = h = 0: whole image."""
+        self._check(self._L.pt_set_tile(self._ctx, x0, y0, w, h))
+
     def setAccumMode(self, mode):
         self._check(self._L.pt_set_accum_mode(self._ctx, mode))
 
@@ -224,6 +251,16 @@ class HipRaytracing:
 
     def writeImageFromDevice(self, dev_ptr: int):
         self._check(self._L.pt_write_image_from_device(self._ctx, C.c_void_p(dev_ptr)))
+
+    def saveCheckpoint(self, path: str):
+        """Accumulation image + frame index + sampling parameters (pt_save_checkpoint)."""
+        self._check(self._L.pt_save_checkpoint(self._ctx, os.fsencode(path)))
+
+    def loadCheckpoint(self, path: str):
+        self._check(self._L.pt_load_checkpoint(self._ctx, os.fsencode(path)))
+        w, h = C.c_uint32(0), C.c_uint32(0)
+        self._check(self._L.pt_image_extent(self._ctx, C.byref(w), C.byref(h)))
+        self.width, self.height = int(w.value), int(h.value)  # the checkpoint's extent replaces the context's
 
     def setProfiling(self, flags=PT_PROFILE_KERNELS):
         self._check(self._L.pt_set_profiling(self._ctx, flags))
@@ -278,5 +315,5 @@ class HipRaytracing:
 
 
 __all__ = ["HipRaytracing", "PathTracerError", "Scene", "load_obj", "look_at", "perspective", "inverse4",
-           "reference_camera", "HIT_DTYPE", "NODE_DTYPE", "TRI_DTYPE", "PT_ACCEL_BVH4", "PT_ACCEL_BVH4_PLOC", "PT_ACCEL_BRUTE_FORCE",
+           "reference_camera", "write_png", "write_ppm", "write_pfm", "HIT_DTYPE", "NODE_DTYPE", "TRI_DTYPE", "PT_ACCEL_BVH4", "PT_ACCEL_BVH4_PLOC", "PT_ACCEL_BRUTE_FORCE",
            "PT_ACCUM_MEAN", "PT_ACCUM_SUM", "PT_NO_HIT", "PT_PROFILE_KERNELS", "PT_PROFILE_TRAVERSAL", "PT_PIPELINE_FUSED", "PT_PIPELINE_SPLIT", "PT_PIPELINE_PERSISTENT", "PtStats"]

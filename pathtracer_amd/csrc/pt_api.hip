@@ -46,6 +46,7 @@ struct pt_ctx
 
 	// frame state
 	uint32_t W = 0, H = 0;
+	PtTile tile = { 0, 0, 0, 0 };  // w == 0: the whole image
 	int spp = 10, maxDepth = 20, maxFrames = 1000;
 	float tmin = 0.001f, tmax = 10000.0f;
 	uint32_t seed = 0;
@@ -420,7 +421,31 @@ extern "C" int pt_resize(pt_ctx *c, uint32_t W, uint32_t H)
 	PT_HIP(c, hipMemset(c->image, 0, sizeof(float4) * (size_t)W * H));
 	c->W = W;
 	c->H = H;
+	c->tile = PtTile{ 0, 0, 0, 0 };
 	c->frame = -1;
+	return PT_OK;
+}
+
+extern "C" int pt_image_extent(pt_ctx *c, uint32_t *W, uint32_t *H)
+{
+	if (!c || !W || !H) return fail(c, PT_EINVAL, "pt_image_extent: null argument");
+	*W = c->W;
+	*H = c->H;
+	return PT_OK;
+}
+
+extern "C" int pt_set_tile(pt_ctx *c, uint32_t x0, uint32_t y0, uint32_t w, uint32_t h)
+{
+	if (!c) return fail(nullptr, PT_EINVAL, "null context");
+	if (!c->W) return fail(c, PT_EINVAL, "pt_set_tile: no image (pt_resize)");
+	if (w == 0 && h == 0)
+	{
+		c->tile = PtTile{ 0, 0, 0, 0 };
+		return PT_OK;
+	}
+	if (!w || !h || (uint64_t)x0 + w > c->W || (uint64_t)y0 + h > c->H)
+		return fail(c, PT_EINVAL, "pt_set_tile: %ux%u at (%u,%u) does not fit %ux%u", w, h, x0, y0, c->W, c->H);
+	c->tile = PtTile{ x0, y0, w, h };
 	return PT_OK;
 }
 
@@ -474,7 +499,8 @@ extern "C" int pt_render_frame(pt_ctx *c)
 	c->frame++;  // updateFrame()
 	if (c->maxFrames > 0 && c->frame >= c->maxFrames) return PT_OK;  // "Max frames reached"
 	PT_HIP(c, hipSetDevice(c->device));
-	const uint32_t WH = c->W * c->H;
+	const PtTile tile = c->tile.w ? c->tile : PtTile{ 0, 0, c->W, c->H };
+	const uint32_t WH = tile.w * tile.h;  // pixels this dispatch covers
 	const size_t nPaths = (size_t)WH * c->spp;
 	const bool persistent = (c->pipeline == PT_PIPELINE_PERSISTENT) && !c->brute;
 	const size_t nPadded = (size_t)((WH + PT_WAVE - 1) / PT_WAVE) * PT_WAVE * c->spp;  // whole pixel groups of 64
@@ -523,6 +549,7 @@ extern "C" int pt_render_frame(pt_ctx *c)
 		pa.cam = c->cam;
 		pa.W = c->W;
 		pa.H = c->H;
+		pa.tile = tile;
 		pa.spp = (uint32_t)c->spp;
 		pa.seedWord = c->seed + gframe;
 		pa.centreJitter = gframe == 0;
@@ -541,7 +568,7 @@ extern "C" int pt_render_frame(pt_ctx *c)
 		pa.trav = trav;
 		ptLaunchPaths(pa, c->cfg.bounceWaves, trav != nullptr, s);
 		if (e1) hipEventRecord(e1, s);
-		ptLaunchAccumulateItems(c->q.rad, WH, (uint32_t)c->spp, c->image, (uint32_t)c->frame, c->accumMode, s);
+		ptLaunchAccumulateItems(c->q.rad, tile, c->W, (uint32_t)c->spp, c->image, (uint32_t)c->frame, c->accumMode, s);
 		if (e2)
 		{
 			hipEventRecord(e2, s);
@@ -552,7 +579,7 @@ extern "C" int pt_render_frame(pt_ctx *c)
 		c->framesRendered++;
 		return PT_OK;
 	}
-	ptLaunchGenerate(c->cam, c->W, c->H, (uint32_t)c->spp, c->seed + gframe, gframe == 0, c->q, s);
+	ptLaunchGenerate(c->cam, c->W, c->H, tile, (uint32_t)c->spp, c->seed + gframe, gframe == 0, c->q, s);
 	int in = 0;
 	for (int d = 0; d < c->maxDepth; ++d)
 	{
@@ -585,7 +612,7 @@ extern "C" int pt_render_frame(pt_ctx *c)
 		}
 		in ^= 1;
 	}
-	ptLaunchAccumulate(c->q, WH, (uint32_t)c->spp, c->image, (uint32_t)c->frame, c->accumMode, s);
+	ptLaunchAccumulate(c->q, tile, c->W, (uint32_t)c->spp, c->image, (uint32_t)c->frame, c->accumMode, s);
 	ptLaunchFrameEnd(c->counters, c->maxDepth, c->dStats, c->cfg.waveRays, c->cfg.bounceWaves, s);
 	PT_HIP(c, hipGetLastError());
 	c->framesRendered++;
@@ -646,6 +673,78 @@ extern "C" int pt_write_image_from_device(pt_ctx *c, const void *src)
 	return PT_OK;
 }
 
+// ---- accumulation checkpoint ----
+namespace
+{
+struct CheckpointHeader
+{
+	char magic[8];  // "PTCKPT01"
+	uint32_t W, H;
+	int32_t frame, accumMode;
+	uint32_t firstFrame, frameStride, seed;
+	int32_t spp, maxDepth, maxFrames;
+	float tmin, tmax;
+};
+}  // namespace
+
+extern "C" int pt_save_checkpoint(pt_ctx *c, const char *path)
+{
+	if (!c || !path) return fail(c, PT_EINVAL, "pt_save_checkpoint: null argument");
+	if (!c->image) return fail(c, PT_EINVAL, "pt_save_checkpoint: no image (pt_resize)");
+	std::vector<float> px(4 * (size_t)c->W * c->H);
+	int rc = pt_read_image(c, px.data());
+	if (rc) return rc;
+	CheckpointHeader h;
+	memcpy(h.magic, "PTCKPT01", 8);
+	h.W = c->W;
+	h.H = c->H;
+	h.frame = c->frame;
+	h.accumMode = c->accumMode;
+	h.firstFrame = c->firstFrame;
+	h.frameStride = c->frameStride;
+	h.seed = c->seed;
+	h.spp = c->spp;
+	h.maxDepth = c->maxDepth;
+	h.maxFrames = c->maxFrames;
+	h.tmin = c->tmin;
+	h.tmax = c->tmax;
+	FILE *f = fopen(path, "wb");
+	if (!f) return fail(c, PT_EIO, "pt_save_checkpoint: cannot open %s", path);
+	bool ok = fwrite(&h, sizeof(h), 1, f) == 1 && fwrite(px.data(), sizeof(float), px.size(), f) == px.size();
+	ok = (fclose(f) == 0) && ok;
+	return ok ? PT_OK : fail(c, PT_EIO, "pt_save_checkpoint: write to %s failed", path);
+}
+
+extern "C" int pt_load_checkpoint(pt_ctx *c, const char *path)
+{
+	if (!c || !path) return fail(c, PT_EINVAL, "pt_load_checkpoint: null argument");
+	FILE *f = fopen(path, "rb");
+	if (!f) return fail(c, PT_EIO, "pt_load_checkpoint: cannot open %s", path);
+	CheckpointHeader h;
+	if (fread(&h, sizeof(h), 1, f) != 1 || memcmp(h.magic, "PTCKPT01", 8) != 0 || !h.W || !h.H ||
+	    (uint64_t)h.W * h.H > 0x3FFFFFFFull)
+	{
+		fclose(f);
+		return fail(c, PT_EINVAL, "pt_load_checkpoint: %s is not a checkpoint", path);
+	}
+	std::vector<float> px(4 * (size_t)h.W * h.H);
+	size_t got = fread(px.data(), sizeof(float), px.size(), f);
+	fclose(f);
+	if (got != px.size()) return fail(c, PT_EINVAL, "pt_load_checkpoint: %s is truncated", path);
+	if (h.accumMode != PT_ACCUM_MEAN && h.accumMode != PT_ACCUM_SUM) return fail(c, PT_EINVAL, "pt_load_checkpoint: bad accumulation mode");
+	int rc = pt_set_params(c, h.spp, h.maxDepth, h.tmin, h.tmax, h.seed, h.maxFrames);
+	if (rc) return rc;
+	if (!h.frameStride) return fail(c, PT_EINVAL, "pt_load_checkpoint: frame stride 0");
+	rc = pt_resize(c, h.W, h.H);  // also drops frames still in flight
+	if (rc) return rc;
+	c->firstFrame = h.firstFrame;
+	c->frameStride = h.frameStride;
+	c->accumMode = h.accumMode;
+	PT_HIP(c, hipMemcpy(c->image, px.data(), sizeof(float) * px.size(), hipMemcpyHostToDevice));
+	c->frame = h.frame;  // the next pt_render_frame renders frame + 1, as if the run had never stopped
+	return PT_OK;
+}
+
 extern "C" int pt_read_image_srgb8(pt_ctx *c, uint8_t *rgba8)
 {
 	if (!c || !rgba8) return fail(c, PT_EINVAL, "pt_read_image_srgb8: null argument");
@@ -680,7 +779,7 @@ extern "C" int pt_get_stats(pt_ctx *c, PtStats *out)
 	memset(out, 0, sizeof(*out));
 	out->rays_total = h[0];
 	out->rays_last_frame = h[1];
-	out->paths_last_frame = (uint64_t)c->W * c->H * (uint64_t)c->spp;
+	out->paths_last_frame = (c->tile.w ? (uint64_t)c->tile.w * c->tile.h : (uint64_t)c->W * c->H) * (uint64_t)c->spp;
 	out->frames_rendered = c->framesRendered;
 	out->extend_ms_total = c->extendMs;
 	out->extend_launches = c->extendLaunches;
@@ -749,7 +848,7 @@ extern "C" int pt_debug_primary_hits(pt_ctx *c, PtHit *hits)
 	rc = ensureQueues(c, (size_t)WH * c->spp);
 	if (rc) return rc;
 	// frame-0 rays: jitter = pixel centre (raytrace.rgen:38), one sample per pixel
-	ptLaunchGenerate(c->cam, c->W, c->H, 1, c->seed, 1, c->q, c->stream);
+	ptLaunchGenerate(c->cam, c->W, c->H, PtTile{ 0, 0, c->W, c->H }, 1, c->seed, 1, c->q, c->stream);
 	rc = traceQueue0(c, WH, c->tmin, c->tmax);
 	if (rc) return rc;
 	PT_HIP(c, hipMemcpyAsync(hits, c->q.hits, sizeof(PtHit) * (size_t)WH, hipMemcpyDeviceToHost, c->stream));

@@ -667,3 +667,120 @@ extern "C" int pt_write_ppm(const char *path, const uint8_t *rgba8, uint32_t w, 
 	fclose(f);
 	return PT_OK;
 }
+
+// ---------------------------------------------------------------------------- PNG ----
+// 8-bit RGBA PNG with stored (uncompressed) deflate blocks: no dependency, bit-exact round trip.  The
+// reference only presents to a window (main.cpp:1414-1432); SURVEY.md 8(f) row 1 asks for a writer.
+namespace
+{
+uint32_t crc32Update(uint32_t crc, const uint8_t *p, size_t n)
+{
+	static uint32_t table[256];
+	static bool init = false;
+	if (!init)
+	{
+		for (uint32_t i = 0; i < 256; ++i)
+		{
+			uint32_t c = i;
+			for (int k = 0; k < 8; ++k) c = (c & 1u) ? 0xEDB88320u ^ (c >> 1) : c >> 1;
+			table[i] = c;
+		}
+		init = true;
+	}
+	for (size_t i = 0; i < n; ++i) crc = table[(crc ^ p[i]) & 0xFFu] ^ (crc >> 8);
+	return crc;
+}
+
+void put32be(std::vector<uint8_t> &v, uint32_t x)
+{
+	v.push_back((uint8_t)(x >> 24));
+	v.push_back((uint8_t)(x >> 16));
+	v.push_back((uint8_t)(x >> 8));
+	v.push_back((uint8_t)x);
+}
+
+bool writeChunk(FILE *f, const char type[4], const std::vector<uint8_t> &data)
+{
+	std::vector<uint8_t> head;
+	put32be(head, (uint32_t)data.size());
+	head.insert(head.end(), type, type + 4);
+	uint32_t crc = crc32Update(0xFFFFFFFFu, head.data() + 4, 4);
+	crc = crc32Update(crc, data.data(), data.size()) ^ 0xFFFFFFFFu;
+	std::vector<uint8_t> tail;
+	put32be(tail, crc);
+	return fwrite(head.data(), 1, head.size(), f) == head.size() &&
+	       (data.empty() || fwrite(data.data(), 1, data.size(), f) == data.size()) &&
+	       fwrite(tail.data(), 1, 4, f) == 4;
+}
+}  // namespace
+
+extern "C" int pt_write_png(const char *path, const uint8_t *rgba8, uint32_t w, uint32_t h)
+{
+	if (!path || !rgba8 || w == 0 || h == 0 || (uint64_t)w * h * 4 + h > 0x7FFFFFF0ull)
+	{
+		g_seamError = "pt_write_png: bad argument";
+		return PT_EINVAL;
+	}
+	FILE *f = fopen(path, "wb");
+	if (!f)
+	{
+		g_seamError = std::string("pt_write_png: cannot open ") + path;
+		return PT_EIO;
+	}
+	static const uint8_t sig[8] = { 0x89, 'P', 'N', 'G', 0x0D, 0x0A, 0x1A, 0x0A };
+	bool ok = fwrite(sig, 1, 8, f) == 8;
+	std::vector<uint8_t> ihdr;
+	put32be(ihdr, w);
+	put32be(ihdr, h);
+	const uint8_t fmt[5] = { 8, 6, 0, 0, 0 };  // 8 bits, RGBA, deflate, adaptive filtering (type 0 used), no interlace
+	ihdr.insert(ihdr.end(), fmt, fmt + 5);
+	ok = ok && writeChunk(f, "IHDR", ihdr);
+	const uint8_t srgb[1] = { 0 };  // rendering intent: the bytes are sRGB-encoded (pt_read_image_srgb8)
+	ok = ok && writeChunk(f, "sRGB", std::vector<uint8_t>(srgb, srgb + 1));
+	// raw scanlines: filter byte 0 + row
+	const size_t stride = (size_t)w * 4 + 1, rawLen = stride * h;
+	std::vector<uint8_t> raw(rawLen);
+	for (uint32_t y = 0; y < h; ++y)
+	{
+		raw[y * stride] = 0;
+		memcpy(&raw[y * stride + 1], rgba8 + (size_t)y * w * 4, (size_t)w * 4);
+	}
+	uint32_t s1 = 1, s2 = 0;  // adler32
+	for (size_t i = 0; i < rawLen;)
+	{
+		size_t n = rawLen - i < 5552 ? rawLen - i : 5552;
+		for (size_t k = 0; k < n; ++k)
+		{
+			s1 += raw[i + k];
+			s2 += s1;
+		}
+		s1 %= 65521u;
+		s2 %= 65521u;
+		i += n;
+	}
+	std::vector<uint8_t> z;
+	z.reserve(rawLen + rawLen / 65535 * 5 + 16);
+	z.push_back(0x78);
+	z.push_back(0x01);
+	for (size_t i = 0; i < rawLen;)
+	{
+		size_t n = rawLen - i < 65535 ? rawLen - i : 65535;
+		z.push_back(i + n == rawLen ? 1 : 0);  // BFINAL, BTYPE = 00 (stored)
+		z.push_back((uint8_t)(n & 0xFF));
+		z.push_back((uint8_t)(n >> 8));
+		z.push_back((uint8_t)(~n & 0xFF));
+		z.push_back((uint8_t)((~n >> 8) & 0xFF));
+		z.insert(z.end(), raw.begin() + (long)i, raw.begin() + (long)(i + n));
+		i += n;
+	}
+	put32be(z, (s2 << 16) | s1);
+	ok = ok && writeChunk(f, "IDAT", z);
+	ok = ok && writeChunk(f, "IEND", std::vector<uint8_t>());
+	ok = (fclose(f) == 0) && ok;
+	if (!ok)
+	{
+		g_seamError = std::string("pt_write_png: write failed: ") + path;
+		return PT_EIO;
+	}
+	return PT_OK;
+}

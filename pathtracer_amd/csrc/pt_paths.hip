@@ -58,7 +58,7 @@ __global__ void __launch_bounds__(PT_WAVE) k_paths(PtPathsArgs a)
 	const unsigned long long laneBit = 1ull << lane, lanesBelow = laneBit - 1ull;
 	uint32_t *mySpill = a.spill + (size_t)blockIdx.x * PT_WAVE + lane;
 	const float tmin = a.tmin, tmax = a.tmax;
-	const uint32_t WH = a.W * a.H;
+	const uint32_t WH = a.tile.w * a.tile.h;  // pixels of the tile this dispatch covers
 	const uint32_t totalItems = ((WH + PT_WAVE - 1) / PT_WAVE) * a.spp;
 
 	// ---- generator (wave-uniform cursors + the per-lane raygen seed chain) ----
@@ -246,9 +246,10 @@ __global__ void __launch_bounds__(PT_WAVE) k_paths(PtPathsArgs a)
 							needSeed = false;
 							uint32_t p = g * PT_WAVE + lane;
 							genValid = p < WH;
-							genPy = p / a.W;
-							genPx = p - genPy * a.W;
-							genSeed = pt_tea(p, a.seedWord);  // rgen:28 with val1 = seed + global frame
+							const uint32_t ty = p / a.tile.w;
+							genPy = a.tile.y0 + ty;
+							genPx = a.tile.x0 + (p - ty * a.tile.w);
+							genSeed = pt_tea(genPy * a.W + genPx, a.seedWord);  // rgen:28 with val1 = seed + global frame
 							if (i)
 							{
 								uint2 ac = a.lcgSkip[i];  // state after 2*i lcg steps = A * s + C
@@ -383,13 +384,15 @@ __global__ void __launch_bounds__(PT_WAVE) k_paths(PtPathsArgs a)
 	}
 }
 
-// k_accumulate for the item-major radiance layout of k_paths: q(p, i) = ((p / 64) * spp + i) * 64 + p % 64.
+// k_accumulate for the item-major radiance layout of k_paths: q(t, i) = ((t / 64) * spp + i) * 64 + t % 64,
+// t = pixel index inside the tile.
 __global__ void __launch_bounds__(256)
-    k_accumulate_items(const float4 *rad, uint32_t WH, uint32_t spp, float4 *image, uint32_t lframe, int mode)
+    k_accumulate_items(const float4 *rad, PtTile tile, uint32_t W, uint32_t spp, float4 *image, uint32_t lframe, int mode)
 {
-	uint32_t p = blockIdx.x * 256 + threadIdx.x;
-	if (p >= WH) return;
-	const size_t base = (size_t)(p / PT_WAVE) * spp * PT_WAVE + (p % PT_WAVE);
+	uint32_t t = blockIdx.x * 256 + threadIdx.x;
+	if (t >= tile.w * tile.h) return;
+	const uint32_t p = (tile.y0 + t / tile.w) * W + tile.x0 + t % tile.w;  // image pixel of tile pixel t
+	const size_t base = (size_t)(t / PT_WAVE) * spp * PT_WAVE + (t % PT_WAVE);
 	float ax = 0.0f, ay = 0.0f, az = 0.0f;
 	for (uint32_t i = 0; i < spp; ++i)
 	{
@@ -423,8 +426,8 @@ void ptLaunchPaths(const PtPathsArgs &args, uint32_t waves, bool stats, hipStrea
 	else k_paths<false><<<waves, PT_WAVE, 0, s>>>(args);
 }
 
-void ptLaunchAccumulateItems(const float4 *rad, uint32_t WH, uint32_t spp, float4 *image, uint32_t lframe, int mode,
-                             hipStream_t s)
+void ptLaunchAccumulateItems(const float4 *rad, PtTile tile, uint32_t W, uint32_t spp, float4 *image, uint32_t lframe,
+                             int mode, hipStream_t s)
 {
-	k_accumulate_items<<<(WH + 255) / 256, 256, 0, s>>>(rad, WH, spp, image, lframe, mode);
+	k_accumulate_items<<<(tile.w * tile.h + 255) / 256, 256, 0, s>>>(rad, tile, W, spp, image, lframe, mode);
 }

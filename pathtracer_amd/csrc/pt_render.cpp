@@ -2,7 +2,7 @@
 // (initVulkan -> loadModel -> buildBlas/buildTlas -> mainLoop{updateUniformBuffer, raytrace})
 // without the window: loads an OBJ, renders N frames, writes the accumulation image.
 //
-//   pt_render scene.obj [-w 800] [-h 600] [-spp 10] [-frames 100] [-depth 20] [-seed 0] [-o out.pfm|out.ppm]
+//   pt_render scene.obj [-w 800] [-h 600] [-spp 10] [-frames 100] [-depth 20] [-seed 0] [-o out.pfm|out.ppm|out.png]
 //
 // Defaults are the reference's constants (VulkanUtils.h:11-15, raytrace.rgen:22-23).
 #include <chrono>
@@ -30,7 +30,7 @@ int main(int argc, char **argv)
 	pt_ctx *ctx = nullptr;
 	if (argc < 2)
 	{
-		fprintf(stderr, "usage: %s scene.obj [-w W] [-h H] [-spp S] [-frames F] [-depth D] [-seed X] [-o out.pfm|.ppm]\n", argv[0]);
+		fprintf(stderr, "usage: %s scene.obj [-w W] [-h H] [-spp S] [-frames F] [-depth D] [-seed X] [-o out.pfm|.ppm|.png]\n", argv[0]);
 		return EXIT_FAILURE;
 	}
 	std::string objPath = argv[1], out = "out.pfm";
@@ -78,11 +78,13 @@ int main(int argc, char **argv)
 	CHECK(pt_get_stats(ctx, &st));
 	printf("%u triangles, BVH4 %u nodes (build %.3f ms); %d frames x %d spp at %ux%u: %.3f s, %.1f Mrays/s, %.2f spp/px/s\n",
 	       st.bvh_tris, st.bvh_nodes, st.build_ms, frames, spp, W, H, sec, st.rays_total / sec / 1e6, frames * spp / sec);
-	if (out.size() > 4 && out.substr(out.size() - 4) == ".ppm")
+	const std::string ext = out.size() > 4 ? out.substr(out.size() - 4) : "";
+	if (ext == ".ppm" || ext == ".png")
 	{
 		std::vector<uint8_t> px(4 * (size_t)W * H);
 		CHECK(pt_read_image_srgb8(ctx, px.data()));
-		CHECK(pt_write_ppm(out.c_str(), px.data(), W, H));
+		if (ext == ".png") CHECK(pt_write_png(out.c_str(), px.data(), W, H));
+		else CHECK(pt_write_ppm(out.c_str(), px.data(), W, H));
 	}
 	else
 	{

@@ -6,6 +6,13 @@
 #define PT_SPILL_STACK 72   // traversal stack entries per lane beyond the LDS-resident ones
 #define PT_CHUNK 1024u      // queue records per chunk (work-claim and compaction granularity)
 
+// Sub-rectangle of the image a dispatch covers (pt_set_tile; default = the whole image).  Tile pixel t maps to
+// image pixel (x0 + t % w, y0 + t / w); seeds always use the full-image linear index y * W + x (rgen:28).
+struct PtTile
+{
+	uint32_t x0, y0, w, h;
+};
+
 // Per-frame device counters, zeroed by k_frame_begin.  count[d] = rays queued for bounce d.
 struct PtFrameCounters
 {
@@ -39,7 +46,7 @@ struct PtLaunchCfg
 void ptLaunchFrameBegin(PtFrameCounters *fc, uint32_t nPaths, int fused, hipStream_t s);
 void ptLaunchFrameEnd(const PtFrameCounters *fc, int depth, unsigned long long *stats, uint32_t *waveRays,
                       uint32_t nWaveRays, hipStream_t s);
-void ptLaunchGenerate(const PtCamera &cam, uint32_t W, uint32_t H, uint32_t spp, uint32_t seedWord, int centreJitter,
+void ptLaunchGenerate(const PtCamera &cam, uint32_t W, uint32_t H, PtTile tile, uint32_t spp, uint32_t seedWord, int centreJitter,
                       const PtQueues &q, hipStream_t s);
 void ptLaunchExtend(const PtSceneDev &sc, bool brute, const uint32_t *count, uint32_t *head, const float4 *rayO,
                     const float4 *rayD, float4 *hits, float tmin, float tmax, const PtLaunchCfg &cfg,
@@ -53,13 +60,15 @@ void ptLaunchBounce(const PtSceneDev &sc, const PtQueues &q, int in, PtFrameCoun
                     hipStream_t s);
 // Persistent path kernel (pt_paths.hip): one launch traces every path of the frame from camera ray to
 // termination.  Buffers: ringO/ringD = waves * PT_PATHS_RING records (wave-private survivor rings), state and
-// rad = ceil(W*H/64) * 64 * spp records in item-major order q = ((pixel / 64) * spp + sample) * 64 + pixel % 64.
+// rad = ceil(tile pixels/64) * 64 * spp records in item-major order q = ((t / 64) * spp + sample) * 64 + t % 64
+// (t = pixel index inside the tile).
 #define PT_PATHS_RING 256u
 struct PtPathsArgs
 {
 	PtSceneDev sc;
 	PtCamera cam;
 	uint32_t W, H, spp, seedWord;
+	PtTile tile;
 	int centreJitter, maxDepth;
 	float tmin, tmax;
 	const uint2 *lcgSkip;  // [spp]: (A, C) with lcg^(2i)(s) = A * s + C
@@ -71,9 +80,9 @@ struct PtPathsArgs
 	unsigned long long *trav;  // traversal statistics (stats variant only)
 };
 void ptLaunchPaths(const PtPathsArgs &args, uint32_t waves, bool stats, hipStream_t s);
-void ptLaunchAccumulateItems(const float4 *rad, uint32_t WH, uint32_t spp, float4 *image, uint32_t lframe, int mode,
+void ptLaunchAccumulateItems(const float4 *rad, PtTile tile, uint32_t W, uint32_t spp, float4 *image, uint32_t lframe, int mode,
                              hipStream_t s);
-void ptLaunchAccumulate(const PtQueues &q, uint32_t WH, uint32_t spp, float4 *image, uint32_t lframe, int mode,
+void ptLaunchAccumulate(const PtQueues &q, PtTile tile, uint32_t W, uint32_t spp, float4 *image, uint32_t lframe, int mode,
                         hipStream_t s);
 void ptLaunchDebugRng(uint32_t n, const uint32_t *v0, const uint32_t *v1, uint32_t nSteps, uint32_t *outTea,
                       uint32_t *outLcg, float *outUnit, hipStream_t s);

@@ -147,14 +147,14 @@ __device__ __forceinline__ PtHit traverseBrute(const PtSceneDev &sc, float3x o, 
 
 // ------------------------------------------------------------------------ generate ----
 __global__ void __launch_bounds__(kBlock)
-    k_generate(PtCamera cam, uint32_t W, uint32_t H, uint32_t spp, uint32_t seedWord, int centreJitter, float4 *rayO,
-               float4 *rayD, float4 *thr, float4 *rad)
+    k_generate(PtCamera cam, uint32_t W, uint32_t H, PtTile tile, uint32_t spp, uint32_t seedWord, int centreJitter,
+               float4 *rayO, float4 *rayD, float4 *thr, float4 *rad)
 {
 	uint32_t p = blockIdx.x * kBlock + threadIdx.x;
-	const uint32_t WH = W * H;
+	const uint32_t WH = tile.w * tile.h;  // paths are numbered inside the tile
 	if (p >= WH) return;
-	uint32_t px = p % W, py = p / W;
-	uint32_t seed = pt_tea(p, seedWord);  // raytrace.rgen:28 with val1 = seed + global frame
+	uint32_t px = tile.x0 + p % tile.w, py = tile.y0 + p / tile.w;
+	uint32_t seed = pt_tea(py * W + px, seedWord);  // raytrace.rgen:28 with val1 = seed + global frame
 	for (uint32_t i = 0; i < spp; ++i)
 	{
 		float r1 = pt_rnd(seed);
@@ -314,14 +314,16 @@ __global__ void __launch_bounds__(kBlock)
 // ---------------------------------------------------------------------- accumulate ----
 // raytrace.rgen:82-95.  mode PT_ACCUM_MEAN: running mean with a = 1/(lframe+1); PT_ACCUM_SUM: raw sums.
 __global__ void __launch_bounds__(kBlock)
-    k_accumulate(const float4 *rad, uint32_t WH, uint32_t spp, float4 *image, uint32_t lframe, int mode)
+    k_accumulate(const float4 *rad, PtTile tile, uint32_t W, uint32_t spp, float4 *image, uint32_t lframe, int mode)
 {
-	uint32_t p = blockIdx.x * kBlock + threadIdx.x;
-	if (p >= WH) return;
+	uint32_t t = blockIdx.x * kBlock + threadIdx.x;
+	const uint32_t WH = tile.w * tile.h;
+	if (t >= WH) return;
+	const uint32_t p = (tile.y0 + t / tile.w) * W + tile.x0 + t % tile.w;  // image pixel of tile pixel t
 	float ax = 0.0f, ay = 0.0f, az = 0.0f;
 	for (uint32_t i = 0; i < spp; ++i)
 	{
-		float4 L = rad[(size_t)i * WH + p];
+		float4 L = rad[(size_t)i * WH + t];
 		ax += L.x;
 		ay += L.y;
 		az += L.z;
@@ -442,10 +444,10 @@ void ptLaunchFrameEnd(const PtFrameCounters *fc, int depth, unsigned long long *
 	k_frame_end<<<1, 256, 0, s>>>(fc, depth, stats, waveRays, nWaveRays);
 }
 
-void ptLaunchGenerate(const PtCamera &cam, uint32_t W, uint32_t H, uint32_t spp, uint32_t seedWord, int centreJitter,
-                      const PtQueues &q, hipStream_t s)
+void ptLaunchGenerate(const PtCamera &cam, uint32_t W, uint32_t H, PtTile tile, uint32_t spp, uint32_t seedWord,
+                      int centreJitter, const PtQueues &q, hipStream_t s)
 {
-	k_generate<<<divUp((size_t)W * H, kBlock), kBlock, 0, s>>>(cam, W, H, spp, seedWord, centreJitter, q.rayO[0],
+	k_generate<<<divUp((size_t)tile.w * tile.h, kBlock), kBlock, 0, s>>>(cam, W, H, tile, spp, seedWord, centreJitter, q.rayO[0],
 	                                                          q.rayD[0], q.thr[0], q.rad);
 }
 
@@ -477,10 +479,10 @@ void ptLaunchShade(const PtSceneDev &sc, const uint8_t *primEmissive, const uint
 	                                                q.rad, lastBounce);
 }
 
-void ptLaunchAccumulate(const PtQueues &q, uint32_t WH, uint32_t spp, float4 *image, uint32_t lframe, int mode,
+void ptLaunchAccumulate(const PtQueues &q, PtTile tile, uint32_t W, uint32_t spp, float4 *image, uint32_t lframe, int mode,
                         hipStream_t s)
 {
-	k_accumulate<<<divUp(WH, kBlock), kBlock, 0, s>>>(q.rad, WH, spp, image, lframe, mode);
+	k_accumulate<<<divUp((size_t)tile.w * tile.h, kBlock), kBlock, 0, s>>>(q.rad, tile, W, spp, image, lframe, mode);
 }
 
 void ptLaunchDebugRng(uint32_t n, const uint32_t *v0, const uint32_t *v1, uint32_t nSteps, uint32_t *outTea,

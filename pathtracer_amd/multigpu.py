@@ -22,6 +22,20 @@ def global_frames(rank: int, world: int, frames_per_rank: int):
     return [first + k * stride for k in range(frames_per_rank)]
 
 
+def tile_schedule(rank: int, world: int, width: int, height: int):
+    """Image-tile split: rank r renders the r-th of `world` column strips,
+    (x0, y0, w, h) for pt_set_tile.  Strip widths differ by at most one pixel; every rank renders the SAME
+    global frames (schedule first=0, stride=1) into an image that is zero outside its strip, so the strips
+    combine with the same reduce(sum) as sample streams and the result does not depend on `world` at all."""
+    if not (0 <= rank < world):
+        raise ValueError(f"rank {rank} outside world of {world}")
+    if world > width:
+        raise ValueError(f"{world} strips do not fit {width} columns")
+    base, extra = divmod(width, world)
+    x0 = rank * base + min(rank, extra)
+    return x0, 0, base + (1 if rank < extra else 0), height
+
+
 def reduce_sum_image(image_tensor, dist, dst: int = 0):
     """In-place reduce(sum) of the per-rank sum images onto `dst` (torch.distributed module passed in
     so the same code runs over nccl(=RCCL) and gloo)."""

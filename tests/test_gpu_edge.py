@@ -123,3 +123,42 @@ def test_error_codes(rt, pa, cornell):
         rt.setParams(tmin=-1.0)
     with pytest.raises(pa.PathTracerError):
         pa.HipRaytracing(4096)
+
+
+def test_checkpoint_resume_is_bit_identical(pa, cornell, tmp_path):
+    """pt_save_checkpoint / pt_load_checkpoint: 2 frames, save, a NEW context loads
+    and renders 3 more == 5 frames in one go, bit for bit (frame index, seed, schedule, mode all restored)."""
+    from pathtracer_amd.api import PT_ACCUM_SUM
+    W, H = 80, 45
+    view, proj = pa.reference_camera(W, H)
+
+    def fresh():
+        r = pa.HipRaytracing(0)
+        r.buildBlas(cornell)
+        r.setCamera(view, proj)
+        return r
+
+    a = fresh()
+    a.resize(W, H)
+    a.setParams(spp_per_frame=3, max_depth=6, seed=11, max_frames=0)
+    a.setFrameSchedule(first=1, stride=2)
+    a.setAccumMode(PT_ACCUM_SUM)
+    a.raytrace(5)
+    want = a.readImage()
+    a.resetFrame()
+    a.raytrace(2)
+    ck = str(tmp_path / "acc.ckpt")
+    a.saveCheckpoint(ck)
+    a.cleanup()
+    b = fresh()
+    b.loadCheckpoint(ck)
+    assert b.frame == 1
+    b.raytrace(3)
+    assert b.frame == 4
+    assert np.array_equal(bits(b.readImage()), bits(want))
+    with pytest.raises(pa.PathTracerError):
+        b.loadCheckpoint(str(tmp_path / "missing.ckpt"))
+    open(tmp_path / "bad.ckpt", "wb").write(b"not a checkpoint at all" * 10)
+    with pytest.raises(pa.PathTracerError):
+        b.loadCheckpoint(str(tmp_path / "bad.ckpt"))
+    b.cleanup()

@@ -153,3 +153,51 @@ def test_loader_empty_obj(pa, tmp_path):
     p.write_text("# nothing\n")
     sc = pa.load_obj(str(p))
     assert sc.indices.size == 0 and sc.vertices.shape[0] == 0 and sc.materials.shape == (1, 6)
+
+
+def _decode_png(path):
+    """Minimal PNG reader for 8-bit RGBA, filter type 0 (what pt_write_png emits); checks every CRC."""
+    import struct
+    import zlib
+    data = open(path, "rb").read()
+    assert data[:8] == b"\x89PNG\r\n\x1a\n"
+    pos, chunks = 8, []
+    while pos < len(data):
+        n, typ = struct.unpack(">I4s", data[pos:pos + 8])
+        body = data[pos + 8:pos + 8 + n]
+        (crc,) = struct.unpack(">I", data[pos + 8 + n:pos + 12 + n])
+        assert crc == (zlib.crc32(typ + body) & 0xFFFFFFFF), typ
+        chunks.append((typ, body))
+        pos += 12 + n
+    assert [c[0] for c in chunks] == [b"IHDR", b"sRGB", b"IDAT", b"IEND"]
+    w, h, depth, ctype, comp, flt, inter = struct.unpack(">IIBBBBB", chunks[0][1])
+    assert (depth, ctype, comp, flt, inter) == (8, 6, 0, 0, 0)
+    raw = np.frombuffer(zlib.decompress(chunks[2][1]), dtype=np.uint8).reshape(h, 1 + 4 * w)
+    assert np.all(raw[:, 0] == 0)
+    return raw[:, 1:].reshape(h, w, 4)
+
+
+@pytest.mark.parametrize("shape", [(1, 1), (5, 7), (300, 257)])  # the last one needs several stored blocks
+def test_png_writer_round_trip(pa, tmp_path, shape):
+    rng = np.random.default_rng(shape[0])
+    img = rng.integers(0, 256, size=(shape[0], shape[1], 4), dtype=np.uint8)
+    path = tmp_path / "a.png"
+    pa.write_png(str(path), img)
+    assert np.array_equal(_decode_png(path), img)
+    with pytest.raises(pa.PathTracerError):
+        pa.write_png(str(tmp_path / "no_such_dir" / "a.png"), img)
+
+
+def test_ppm_and_pfm_writers(pa, tmp_path):
+    rng = np.random.default_rng(1)
+    img8 = rng.integers(0, 256, size=(4, 6, 4), dtype=np.uint8)
+    pa.write_ppm(str(tmp_path / "a.ppm"), img8)
+    blob = open(tmp_path / "a.ppm", "rb").read()
+    assert blob.startswith(b"P6\n6 4\n255\n") and blob[len(b"P6\n6 4\n255\n"):] == img8[..., :3].tobytes()
+    imgf = rng.normal(size=(4, 6, 4)).astype(np.float32)
+    pa.write_pfm(str(tmp_path / "a.pfm"), imgf)
+    blob = open(tmp_path / "a.pfm", "rb").read()
+    head = b"PF\n6 4\n-1.0\n"
+    assert blob.startswith(head)
+    got = np.frombuffer(blob[len(head):], dtype="<f4").reshape(4, 6, 3)
+    assert np.array_equal(got, imgf[::-1, :, :3])  # PFM stores the bottom row first
