@@ -103,6 +103,24 @@ int pt_synchronize(pt_ctx *ctx);
 
 /* ---- scene + acceleration structure ---------------------------------------------------- */
 
+/* VulkanRaytracing::buildTlas / createInstancesBuffer (VulkanRaytracing.cpp:382-527): the instances of the one
+ * bottom-level structure.  transform = VkTransformMatrixKHR (object-to-world, 3x4 row-major); custom_index must
+ * be 0 (the reference has one Model, raytrace.rchit:27); mask is kept for layout only (every instance is visible,
+ * as with the reference's 0xFF).  n = 0 (default) is the reference's single identity instance and costs nothing.
+ * Semantics (Vulkan spec + raytrace.rchit:45-46): the ray is taken into object space with the world-to-object
+ * matrix (glm::inverse of the 4x4, fp32 cofactors -- this build's definition of gl_WorldToObjectEXT) WITHOUT
+ * renormalising the direction, so hit distances compare across instances; ties go to the lower instance index;
+ * hit position = ObjectToWorld * p, normal = normalize(n * WorldToObject).  Call before pt_build_accel (which
+ * builds the top-level BVH4 over the instances' world boxes).  Instanced scenes render on
+ * PT_PIPELINE_PERSISTENT. */
+typedef struct PtInstance
+{
+	float transform[12];
+	uint32_t custom_index;
+	uint32_t mask;
+} PtInstance;
+int pt_set_instances(pt_ctx *ctx, const PtInstance *instances, uint32_t n);
+
 /* PathTracer::createModelBuffers (main.cpp:1192-1279): uploads the four scene buffers the
  * `Model` address table points at.  n_indices must be a multiple of 3; mat_indices has
  * n_indices/3 entries, each < n_materials.  Host pointers are copied; nothing is borrowed. */

@@ -15,7 +15,8 @@ NONE = 0xFFFFFFFF
 
 class Scene(C.Structure):
     _fields_ = [("verts", C.c_void_p), ("nVerts", C.c_uint32), ("indices", C.c_void_p), ("nIdx", C.c_uint32),
-                ("materials", C.c_void_p), ("nMat", C.c_uint32), ("matIdx", C.c_void_p)]
+                ("materials", C.c_void_p), ("nMat", C.c_uint32), ("matIdx", C.c_void_p),
+                ("instances", C.c_void_p), ("nInst", C.c_uint32)]
 
 
 class Params(C.Structure):
@@ -86,6 +87,7 @@ def _bind(L):
     L.pto_render_pixels.argtypes = [C.POINTER(Scene), vp, vp, vp, u32, u32, C.POINTER(Params), u32, vp, u32, vp]
     L.pto_primary_hits.argtypes = [C.POINTER(Scene), vp, vp, vp, u32, u32, f32, f32, vp]
     L.pto_trace_rays.argtypes = [C.POINTER(Scene), vp, vp, u32, f32, f32, vp]
+    L.pto_trace_rays_inst.argtypes = [C.POINTER(Scene), vp, vp, u32, f32, f32, vp, vp]
     L.pto_morton_codes.argtypes = [C.POINTER(Scene), vp, vp, vp]
     L.pto_morton_order.argtypes = [vp, u32, vp]
     L.pto_srgb8.argtypes = [vp, u32, vp]
@@ -154,17 +156,40 @@ def reference_camera(W, H):
     return v, p
 
 
+def instance_world_to_object(o2w):
+    """World-to-object 3x4 (row-major) of an object-to-world 3x4 (row-major): glm::inverse of the 4x4 whose
+    last row is (0,0,0,1), i.e. what gl_WorldToObjectEXT holds (the Vulkan spec leaves the precision of that
+    inverse to the implementation; this build DEFINES it as glm's cofactor algorithm in fp32)."""
+    a = np.ascontiguousarray(o2w, dtype=np.float32).reshape(3, 4)
+    m = np.zeros((4, 4), dtype=np.float32)  # column-major float[16] as glm: m[c][r]
+    m[:, :3] = a.T
+    m[3, 3] = 1.0
+    inv = inverse4(m.reshape(16)).reshape(4, 4)  # inv[c][r]
+    return np.ascontiguousarray(inv[:, :3].T, dtype=np.float32).reshape(12)
+
+
 class OracleScene:
     """Holds the reference-layout buffers (Vertex 44 B, Material 24 B) and an optional BVH."""
 
-    def __init__(self, vertices, indices, materials, mat_indices, use_bvh=None):
+    def __init__(self, vertices, indices, materials, mat_indices, use_bvh=None, instances=None):
         self.vertices = np.ascontiguousarray(vertices, dtype=np.float32).reshape(-1, 11)
         self.indices = np.ascontiguousarray(indices, dtype=np.uint32).reshape(-1)
         self.materials = np.ascontiguousarray(materials, dtype=np.float32).reshape(-1, 6)
         self.mat_indices = np.ascontiguousarray(mat_indices, dtype=np.uint32).reshape(-1)
         assert self.indices.size % 3 == 0 and self.mat_indices.size == self.indices.size // 3
+        # instances: (n, 12) object-to-world 3x4 row-major transforms; the world-to-object halves are derived
+        # here with the oracle's glm::inverse restatement, as the product derives them with its own
+        self.instances = None
+        if instances is not None and len(instances):
+            o2w = np.ascontiguousarray(instances, dtype=np.float32).reshape(-1, 12)
+            self.instances = np.zeros((o2w.shape[0], 24), dtype=np.float32)
+            self.instances[:, :12] = o2w
+            for i in range(o2w.shape[0]):
+                self.instances[i, 12:] = instance_world_to_object(o2w[i])
         self.c = Scene(_p(self.vertices), self.vertices.shape[0], _p(self.indices), self.indices.size,
-                       _p(self.materials), self.materials.shape[0], _p(self.mat_indices))
+                       _p(self.materials), self.materials.shape[0], _p(self.mat_indices),
+                       _p(self.instances) if self.instances is not None else None,
+                       0 if self.instances is None else self.instances.shape[0])
         if use_bvh is None:
             use_bvh = self.indices.size // 3 > 64
         self.bvh = lib().pto_bvh_build(C.byref(self.c)) if use_bvh else None
@@ -192,6 +217,15 @@ class OracleScene:
         hits = np.zeros(r.shape[0], dtype=HIT_DTYPE)
         lib().pto_trace_rays(C.byref(self.c), None if brute else self.bvh, _p(r), r.shape[0], tmin, tmax, _p(hits))
         return hits
+
+    def trace_inst(self, rays, tmin=1e-3, tmax=1e4, brute=False):
+        """(hits, instance index per hit) for an instanced scene."""
+        r = np.ascontiguousarray(rays, dtype=np.float32).reshape(-1, 6)
+        hits = np.zeros(r.shape[0], dtype=HIT_DTYPE)
+        inst = np.zeros(r.shape[0], dtype=np.uint32)
+        lib().pto_trace_rays_inst(C.byref(self.c), None if brute else self.bvh, _p(r), r.shape[0], tmin, tmax, _p(hits),
+                                  _p(inst))
+        return hits, inst
 
     def render(self, view, proj, W, H, frames, spp_per_frame=10, max_depth=20, tmin=1e-3, tmax=1e4, seed=0,
                first_frame=0, frame_stride=1, accum_sum=False, nthreads=0, image=None, lframe0=0):

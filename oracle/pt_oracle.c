@@ -275,6 +275,13 @@ typedef struct
 	const float *materials; /* nMat * 6 */
 	uint32_t nMat;
 	const uint32_t *matIdx; /* nIdx/3 */
+	/* Two-level instancing (reference data model: VulkanRaytracing.cpp:382-411 builds ONE
+	 * instance with the identity transform; raytrace.rchit:45-46 already applies gl_ObjectToWorldEXT /
+	 * gl_WorldToObjectEXT).  nInst == 0: the reference's single identity instance (no transform arithmetic at
+	 * all).  Otherwise nInst records of 24 floats: object-to-world 3x4 row-major (VkTransformMatrixKHR), then
+	 * world-to-object 3x4 row-major (glm::inverse of the 4x4, computed by the caller with pto_inverse4). */
+	const float *instances;
+	uint32_t nInst;
 } PtoScene;
 
 typedef struct
@@ -307,9 +314,22 @@ static inline void ray_shear(const float d[3], PtoRayShear *rs)
 /* One ray/triangle test.  Updates *best (t, prim) and the (V, W, det) of the best
  * candidate.  Candidate accepted iff tmin < t and (t < best.t or equal t with a
  * lower primitive id).  Returns 1 if the edge tests passed (for statistics). */
+static inline int tri_test_inst(const float o[3], const PtoRayShear *rs, float tmin, const float *p0, const float *p1,
+                                const float *p2, uint32_t prim, uint32_t inst, float *best_t, uint32_t *best_prim,
+                                uint32_t *best_inst, float *bV, float *bW, float *bDet);
+
 static inline int tri_test(const float o[3], const PtoRayShear *rs, float tmin, const float *p0, const float *p1,
                            const float *p2, uint32_t prim, float *best_t, uint32_t *best_prim, float *bV, float *bW,
                            float *bDet)
+{
+	uint32_t bi = 0;
+	return tri_test_inst(o, rs, tmin, p0, p1, p2, prim, 0u, best_t, best_prim, &bi, bV, bW, bDet);
+}
+
+/* Ties between instances: equal t -> lower instance index, then lower primitive id (order independent). */
+static inline int tri_test_inst(const float o[3], const PtoRayShear *rs, float tmin, const float *p0, const float *p1,
+                                const float *p2, uint32_t prim, uint32_t inst, float *best_t, uint32_t *best_prim,
+                                uint32_t *best_inst, float *bV, float *bW, float *bDet)
 {
 	float A[3] = { p0[0] - o[0], p0[1] - o[1], p0[2] - o[2] };
 	float B[3] = { p1[0] - o[0], p1[1] - o[1], p1[2] - o[2] };
@@ -332,9 +352,10 @@ static inline int tri_test(const float o[3], const PtoRayShear *rs, float tmin, 
 	float Az = rs->Sz * A[rs->kz], Bz = rs->Sz * B[rs->kz], Cz = rs->Sz * C[rs->kz];
 	float T = (U * Az + V * Bz) + W * Cz;
 	float t = T / det;
-	if (t > tmin && (t < *best_t || (t == *best_t && *best_prim != PTO_NONE && prim < *best_prim)))
+	if (t > tmin && (t < *best_t || (t == *best_t && *best_prim != PTO_NONE &&
+	                                 (inst < *best_inst || (inst == *best_inst && prim < *best_prim)))))
 	{
-		*best_t = t; *best_prim = prim; *bV = V; *bW = W; *bDet = det;
+		*best_t = t; *best_prim = prim; *best_inst = inst; *bV = V; *bW = W; *bDet = det;
 	}
 	return 1;
 }
@@ -519,10 +540,77 @@ void pto_intersect_bvh(const PtoBvh *b, const float o[3], const float d[3], floa
 	else { hit->t = tmax; hit->u = 0.0f; hit->v = 0.0f; }
 }
 
-static inline void intersect(const PtoScene *sc, const PtoBvh *bvh, const float o[3], const float d[3], float tmin,
-                             float tmax, PtoHit *hit)
+/* Ray into the object space of an instance: o' = W2O * (o,1), d' = W2O * (d,0), the direction NOT renormalised,
+ * so t means the same in both spaces (Vulkan spec, "Ray Intersection Candidate Determination").  Row r of the
+ * 3x4 matrix m: ((m[r][0]*x + m[r][1]*y) + m[r][2]*z) + m[r][3]. */
+static inline void ray_to_object(const float *w2o, const float o[3], const float d[3], float oo[3], float od[3])
 {
-	if (bvh) pto_intersect_bvh(bvh, o, d, tmin, tmax, hit);
+	for (int r = 0; r < 3; ++r)
+	{
+		const float *m = w2o + 4 * r;
+		oo[r] = ((m[0] * o[0] + m[1] * o[1]) + m[2] * o[2]) + m[3];
+		od[r] = (m[0] * d[0] + m[1] * d[1]) + m[2] * d[2];
+	}
+}
+
+/* Closest hit over all instances: the definition is "every instance, every triangle" -- no top-level
+ * structure on the oracle side; the per-BLAS BVH2 only culls conservatively.  *inst = instance of the hit. */
+void pto_intersect_instances(const PtoScene *sc, const PtoBvh *b, const float o[3], const float d[3], float tmin,
+                             float tmax, PtoHit *hit, uint32_t *inst)
+{
+	float best_t = tmax, bV = 0, bW = 0, bDet = 1;
+	uint32_t best_prim = PTO_NONE, best_inst = 0;
+	uint32_t nTri = sc->nIdx / 3;
+	for (uint32_t ii = 0; ii < sc->nInst; ++ii)
+	{
+		float oo[3], od[3];
+		ray_to_object(sc->instances + 24 * (size_t)ii + 12, o, d, oo, od);
+		PtoRayShear rs;
+		ray_shear(od, &rs);
+		if (!b)
+		{
+			for (uint32_t p = 0; p < nTri; ++p)
+			{
+				const float *p0 = sc->verts + 11 * (size_t)sc->indices[3 * p + 0];
+				const float *p1 = sc->verts + 11 * (size_t)sc->indices[3 * p + 1];
+				const float *p2 = sc->verts + 11 * (size_t)sc->indices[3 * p + 2];
+				tri_test_inst(oo, &rs, tmin, p0, p1, p2, p, ii, &best_t, &best_prim, &best_inst, &bV, &bW, &bDet);
+			}
+			continue;
+		}
+		float inv[3] = { 1.0f / od[0], 1.0f / od[1], 1.0f / od[2] };
+		uint32_t stack[128]; int sp = 0;
+		if (b->nNodes) stack[sp++] = 0;
+		while (sp)
+		{
+			const PtoNode *n = &b->nodes[stack[--sp]];
+			if (!slab(n, oo, inv, tmin, best_t)) continue;
+			if (n->count)
+			{
+				for (uint32_t i = n->first; i < n->first + n->count; ++i)
+				{
+					uint32_t p = b->prims[i];
+					const float *p0 = sc->verts + 11 * (size_t)sc->indices[3 * p + 0];
+					const float *p1 = sc->verts + 11 * (size_t)sc->indices[3 * p + 1];
+					const float *p2 = sc->verts + 11 * (size_t)sc->indices[3 * p + 2];
+					tri_test_inst(oo, &rs, tmin, p0, p1, p2, p, ii, &best_t, &best_prim, &best_inst, &bV, &bW, &bDet);
+				}
+			}
+			else if (sp < 126) { stack[sp++] = n->left; stack[sp++] = n->right; }
+		}
+	}
+	hit->prim = best_prim;
+	*inst = best_inst;
+	if (best_prim != PTO_NONE) { hit->t = best_t; hit->u = bV / bDet; hit->v = bW / bDet; }
+	else { hit->t = tmax; hit->u = 0.0f; hit->v = 0.0f; }
+}
+
+static inline void intersect(const PtoScene *sc, const PtoBvh *bvh, const float o[3], const float d[3], float tmin,
+                             float tmax, PtoHit *hit, uint32_t *inst)
+{
+	*inst = 0;
+	if (sc->nInst) pto_intersect_instances(sc, bvh, o, d, tmin, tmax, hit, inst);
+	else if (bvh) pto_intersect_bvh(bvh, o, d, tmin, tmax, hit);
 	else pto_intersect_brute(sc, o, d, tmin, tmax, hit);
 }
 
@@ -536,7 +624,7 @@ typedef struct
 } PtoParams;
 
 /* raytrace.rchit:24-59.  Returns 1 if the path continues. */
-static inline int closest_hit(const PtoScene *sc, const PtoHit *h, uint32_t *seed, float o[3], float d[3],
+static inline int closest_hit(const PtoScene *sc, const PtoHit *h, uint32_t inst, uint32_t *seed, float o[3], float d[3],
                               float hitValue[3], float emission[3])
 {
 	const float *mat = sc->materials + 6 * (size_t)sc->matIdx[h->prim];
@@ -550,7 +638,22 @@ static inline int closest_hit(const PtoScene *sc, const PtoHit *h, uint32_t *see
 		N[k] = (v0[3 + k] * bx + v1[3 + k] * by) + v2[3 + k] * bz;
 		P[k] = (v0[k] * bx + v1[k] * by) + v2[k] * bz;
 	}
-	/* gl_ObjectToWorldEXT / gl_WorldToObjectEXT are identity (VulkanRaytracing.cpp:391-393) */
+	if (sc->nInst)
+	{
+		/* rchit:45-46: worldHitPos = vec3(gl_ObjectToWorldEXT * vec4(localHitPos, 1.0)) -- mat4x3 * vec4 in glm's
+		 * association (c0*x + c1*y) + (c2*z + c3*w); worldHitNormal = normalize(vec3(localHitNormal *
+		 * gl_WorldToObjectEXT)) -- row vector times matrix: component c = dot(N, column c of W2O). */
+		const float *o2w = sc->instances + 24 * (size_t)inst, *w2o = o2w + 12;
+		float Pw[3], Nw[3];
+		for (int r = 0; r < 3; ++r)
+		{
+			const float *m = o2w + 4 * r;
+			Pw[r] = (m[0] * P[0] + m[1] * P[1]) + (m[2] * P[2] + m[3] * 1.0f);
+			Nw[r] = (N[0] * w2o[0 + r] + N[1] * w2o[4 + r]) + N[2] * w2o[8 + r];
+		}
+		for (int k = 0; k < 3; ++k) { P[k] = Pw[k]; N[k] = Nw[k]; }
+	}
+	/* nInst == 0: gl_ObjectToWorldEXT / gl_WorldToObjectEXT are identity (VulkanRaytracing.cpp:391-393) */
 	normalize3(N, Nn);
 	pto_rnd_unit_vector(seed, rv);
 	nd[0] = Nn[0] + rv[0]; nd[1] = Nn[1] + rv[1]; nd[2] = Nn[2] + rv[2];
@@ -582,15 +685,16 @@ static void render_pixel(const PtoScene *sc, const PtoBvh *bvh, const float invV
 		for (int depth = 0; depth < pp->max_depth; ++depth)
 		{
 			PtoHit h;
+			uint32_t hinst;
 			float hv[3], em[3];
-			intersect(sc, bvh, o, d, pp->tmin, pp->tmax, &h);
+			intersect(sc, bvh, o, d, pp->tmin, pp->tmax, &h, &hinst);
 			++nr;
 			int cont;
 			if (h.prim == PTO_NONE)
 			{
 				hv[0] = hv[1] = hv[2] = 0.0f; em[0] = em[1] = em[2] = 0.0f; cont = 0; /* rmiss */
 			}
-			else cont = closest_hit(sc, &h, &pseed, o, d, hv, em);
+			else cont = closest_hit(sc, &h, hinst, &pseed, o, d, hv, em);
 			for (int k = 0; k < 3; ++k)
 			{
 				accD[k] += em[k] * att[k];
@@ -676,8 +780,9 @@ void pto_primary_hits(const PtoScene *sc, const PtoBvh *bvh, const float view[16
 		for (uint32_t px = 0; px < W; ++px)
 		{
 			float o[3], d[3];
+			uint32_t hinst;
 			pto_camera_ray(invView, invProj, W, H, px, (uint32_t)py, 0.5f, 0.5f, o, d);
-			intersect(sc, bvh, o, d, tmin, tmax, &hits[(size_t)py * W + px]);
+			intersect(sc, bvh, o, d, tmin, tmax, &hits[(size_t)py * W + px], &hinst);
 		}
 }
 
@@ -686,7 +791,20 @@ void pto_trace_rays(const PtoScene *sc, const PtoBvh *bvh, const float *rays, ui
                     PtoHit *hits)
 {
 #pragma omp parallel for schedule(dynamic, 256)
-	for (int64_t i = 0; i < (int64_t)n; ++i) intersect(sc, bvh, rays + 6 * i, rays + 6 * i + 3, tmin, tmax, &hits[i]);
+	for (int64_t i = 0; i < (int64_t)n; ++i)
+	{
+		uint32_t hinst;
+		intersect(sc, bvh, rays + 6 * i, rays + 6 * i + 3, tmin, tmax, &hits[i], &hinst);
+	}
+}
+
+/* Same with the instance index of every hit (instanced scenes): inst[n]. */
+void pto_trace_rays_inst(const PtoScene *sc, const PtoBvh *bvh, const float *rays, uint32_t n, float tmin, float tmax,
+                         PtoHit *hits, uint32_t *inst)
+{
+#pragma omp parallel for schedule(dynamic, 256)
+	for (int64_t i = 0; i < (int64_t)n; ++i)
+		intersect(sc, bvh, rays + 6 * i, rays + 6 * i + 3, tmin, tmax, &hits[i], &inst[i]);
 }
 
 /* ------------------------------------------------------------ BVH build -- */

@@ -45,6 +45,7 @@ SYMBOLS = {
     "pt_synchronize": (_i, [_vp]),
     "pt_upload_scene": (_i, [_vp, _vp, _u32, _vp, _u32, _vp, _u32, _vp]),
     "pt_build_accel": (_i, [_vp, _i]),
+    "pt_set_instances": (_i, [_vp, _vp, _u32]),
     "pt_resize": (_i, [_vp, _u32, _u32]),
     "pt_set_camera": (_i, [_vp, _vp, _vp]),
     "pt_set_params": (_i, [_vp, _i, _i, _f, _f, _u32, _i]),

@@ -23,7 +23,8 @@ NODE_DTYPE = np.dtype([("origin", np.float32, 3), ("scale_x", np.float32), ("chi
                        ("qlo", np.uint8, (3, 4)), ("qhi", np.uint8, (3, 4)), ("scale_yz", np.float32, 2)])
 TRI_DTYPE = np.dtype([("v0", np.float32, 3), ("v1", np.float32, 3), ("v2", np.float32, 3), ("prim", np.uint32),
                       ("pad", np.uint32, 2)])
-assert HIT_DTYPE.itemsize == 16 and NODE_DTYPE.itemsize == 64 and TRI_DTYPE.itemsize == 48
+INSTANCE_DTYPE = np.dtype([("transform", np.float32, 12), ("custom_index", np.uint32), ("mask", np.uint32)])
+assert INSTANCE_DTYPE.itemsize == 56 and HIT_DTYPE.itemsize == 16 and NODE_DTYPE.itemsize == 64 and TRI_DTYPE.itemsize == 48
 
 
 class PathTracerError(RuntimeError):
@@ -186,6 +187,18 @@ class HipRaytracing:
         if scene is not None:
             self.uploadScene(scene)
         self._check(self._L.pt_build_accel(self._ctx, int(flags)))
+
+    def setInstances(self, transforms=None):
+        """createInstancesBuffer (VulkanRaytracing.cpp:382-411): `transforms` = (n, 12) object-to-world 3x4
+        row-major matrices, or None/empty for the reference's single identity instance.  Call before buildBlas."""
+        if transforms is None or len(transforms) == 0:
+            self._check(self._L.pt_set_instances(self._ctx, None, 0))
+            return
+        t = np.ascontiguousarray(transforms, dtype=np.float32).reshape(-1, 12)
+        rec = np.zeros(t.shape[0], dtype=INSTANCE_DTYPE)
+        rec["transform"] = t
+        rec["mask"] = 0xFF
+        self._check(self._L.pt_set_instances(self._ctx, _p(rec), t.shape[0]))
 
     def buildTlas(self):
         """VulkanRaytracing::buildTlas (VulkanRaytracing.cpp:448-527): one identity instance -- nothing

@@ -43,6 +43,10 @@ struct pt_ctx
 	bool haveScene = false, haveAccel = false, brute = false;
 	PtBuildOutput accel;
 	double buildMs = 0.0;
+	// two-level scenes (pt_set_instances): 24 floats per instance (object-to-world 3x4, world-to-object 3x4)
+	std::vector<float> instances;
+	float *dInstances = nullptr;
+	uint32_t nInst = 0, tlasRoot = 0, blasNodes = 0, tlasDepth = 0;
 
 	// frame state
 	uint32_t W = 0, H = 0;
@@ -112,6 +116,9 @@ void freeQueues(pt_ctx *c)
 
 void freeAccel(pt_ctx *c)
 {
+	hipFree(c->dInstances);
+	c->dInstances = nullptr;
+	c->tlasRoot = c->blasNodes = c->tlasDepth = 0;
 	hipFree(c->accel.nodes);
 	hipFree(c->accel.tris);
 	hipFree(c->accel.codes);
@@ -219,6 +226,7 @@ int checkReady(pt_ctx *c, bool needImage)
 // Traces the rays in q.rayO[0]/q.rayD[0][0..n) into q.hits (debug entry points).
 int traceQueue0(pt_ctx *c, uint32_t n, float tmin, float tmax)
 {
+	if (c->nInst) return fail(c, PT_EINVAL, "the ray-level debug entry points trace single-level scenes only (pt_set_instances(ctx, 0, 0))");
 	ptLaunchFrameBegin(c->counters, n, 0, c->stream);
 	ptLaunchExtend(sceneDev(c), c->brute, &c->counters->count[0], &c->counters->headExtend[0], c->q.rayO[0],
 	               c->q.rayD[0], c->q.hits, tmin, tmax, c->cfg, nullptr, c->stream);
@@ -370,6 +378,87 @@ extern "C" int pt_upload_scene(pt_ctx *c, const PtVertex *v, uint32_t nV, const 
 	return PT_OK;
 }
 
+namespace
+{
+// Top-level structure over the instances (buildTlas, VulkanRaytracing.cpp:382-527): world-space box of every
+// instance = transformed corners of the bottom-level root box, a BVH4 over those boxes (same builder, box mode),
+// placed behind the bottom-level nodes in one array so that node references are global.
+int buildTopLevel(pt_ctx *c, int builder)
+{
+	PtNode4 root;
+	PT_HIP(c, hipMemcpy(&root, c->accel.nodes, sizeof(root), hipMemcpyDeviceToHost));
+	float lo[3] = { INFINITY, INFINITY, INFINITY }, hi[3] = { -INFINITY, -INFINITY, -INFINITY };
+	const float scale[3] = { root.scaleX, root.scaleY, root.scaleZ };
+	for (int ch = 0; ch < 4; ++ch)
+	{
+		if (root.child[ch] == PT_EMPTY_CHILD) continue;
+		for (int a = 0; a < 3; ++a)
+		{
+			float l = fmaf((float)((root.qlo[a] >> (8 * ch)) & 0xFFu), scale[a], root.origin[a]);
+			float h = fmaf((float)((root.qhi[a] >> (8 * ch)) & 0xFFu), scale[a], root.origin[a]);
+			lo[a] = fminf(lo[a], l);
+			hi[a] = fmaxf(hi[a], h);
+		}
+	}
+	const uint32_t n = c->nInst;
+	std::vector<float4> bl(n), bh(n);
+	for (uint32_t i = 0; i < n; ++i)
+	{
+		const float *t = &c->instances[(size_t)i * 24];
+		float wl[3] = { INFINITY, INFINITY, INFINITY }, wh[3] = { -INFINITY, -INFINITY, -INFINITY };
+		for (int corner = 0; corner < 8; ++corner)
+		{
+			const float p[3] = { (corner & 1) ? hi[0] : lo[0], (corner & 2) ? hi[1] : lo[1], (corner & 4) ? hi[2] : lo[2] };
+			for (int r = 0; r < 3; ++r)
+			{
+				float w = ((t[4 * r] * p[0] + t[4 * r + 1] * p[1]) + t[4 * r + 2] * p[2]) + t[4 * r + 3];
+				wl[r] = fminf(wl[r], w);
+				wh[r] = fmaxf(wh[r], w);
+			}
+		}
+		bl[i] = make_float4(wl[0], wl[1], wl[2], 0.0f);
+		bh[i] = make_float4(wh[0], wh[1], wh[2], 0.0f);
+	}
+	float4 *dLo = nullptr, *dHi = nullptr;
+	PT_HIP(c, hipMalloc(&dLo, sizeof(float4) * n));
+	PT_HIP(c, hipMalloc(&dHi, sizeof(float4) * n));
+	hipError_t e = hipMemcpy(dLo, bl.data(), sizeof(float4) * n, hipMemcpyHostToDevice);
+	if (e == hipSuccess) e = hipMemcpy(dHi, bh.data(), sizeof(float4) * n, hipMemcpyHostToDevice);
+	PtBuildInput in = { nullptr, nullptr, n, 1, builder };
+	in.boxLo = dLo;
+	in.boxHi = dHi;
+	in.nodeBase = c->blasNodes;
+	in.padExp = 14;  // the object-space hit test and the world-space box disagree by the rounding of two transforms
+	PtBuildOutput top;
+	if (e == hipSuccess) e = ptBuildBvh4(in, top, c->stream);
+	hipFree(dLo);
+	hipFree(dHi);
+	if (e != hipSuccess) return fail(c, PT_EHIP, "pt_build_accel: top-level build failed: %s", hipGetErrorString(e));
+	PtNode4 *all = nullptr;
+	e = hipMalloc(&all, sizeof(PtNode4) * ((size_t)c->blasNodes + top.nNodes));
+	if (e == hipSuccess) e = hipMemcpy(all, c->accel.nodes, sizeof(PtNode4) * c->blasNodes, hipMemcpyDeviceToDevice);
+	if (e == hipSuccess) e = hipMemcpy(all + c->blasNodes, top.nodes, sizeof(PtNode4) * top.nNodes, hipMemcpyDeviceToDevice);
+	if (e == hipSuccess) e = hipMalloc(&c->dInstances, sizeof(float) * c->instances.size());
+	if (e == hipSuccess)
+		e = hipMemcpy(c->dInstances, c->instances.data(), sizeof(float) * c->instances.size(), hipMemcpyHostToDevice);
+	hipFree(top.nodes);
+	hipFree(top.tris);
+	hipFree(top.codes);
+	hipFree(top.order);
+	if (e != hipSuccess)
+	{
+		hipFree(all);
+		return fail(c, PT_EHIP, "pt_build_accel: top-level assembly failed: %s", hipGetErrorString(e));
+	}
+	hipFree(c->accel.nodes);
+	c->accel.nodes = all;
+	c->accel.nNodes = c->blasNodes + top.nNodes;
+	c->tlasRoot = c->blasNodes;
+	c->tlasDepth = top.depth;
+	return PT_OK;
+}
+}  // namespace
+
 extern "C" int pt_build_accel(pt_ctx *c, int flags)
 {
 	if (!c) return fail(nullptr, PT_EINVAL, "null context");
@@ -396,14 +485,65 @@ extern "C" int pt_build_accel(pt_ctx *c, int flags)
 	c->freeEvents.push_back(a);
 	c->freeEvents.push_back(b);
 	if (e != hipSuccess) return fail(c, PT_EHIP, "pt_build_accel: BVH build failed: %s", hipGetErrorString(e));
-	if (3 * c->accel.depth + 1 > 24 + PT_SPILL_STACK)
+	c->blasNodes = c->accel.nNodes;
+	if (c->nInst && !c->brute && c->accel.nNodes)
 	{
-		uint32_t d = c->accel.depth;
+		int rc = buildTopLevel(c, in.builder);
+		if (rc)
+		{
+			freeAccel(c);
+			return rc;
+		}
+	}
+	// stack entries a traversal can need: 3 per level (+ the sentinel), per tree (+ the instance marker)
+	const uint32_t need = 3 * c->accel.depth + 1 + (c->tlasDepth ? 3 * c->tlasDepth + 1 : 0);
+	if (need > PT_STACK_CAPACITY)
+	{
+		uint32_t d = c->accel.depth, dt = c->tlasDepth;
 		freeAccel(c);
-		return fail(c, PT_ELIMIT, "pt_build_accel: BVH4 depth %u exceeds the traversal stack (max %d levels)", d,
-		            (24 + PT_SPILL_STACK - 1) / 3);
+		return fail(c, PT_ELIMIT, "pt_build_accel: BVH4 depth %u (+ top level %u) exceeds the traversal stack (%d entries)", d,
+		            dt, (int)PT_STACK_CAPACITY);
 	}
 	c->haveAccel = true;
+	return PT_OK;
+}
+
+extern "C" int pt_set_instances(pt_ctx *c, const PtInstance *inst, uint32_t n)
+{
+	if (!c) return fail(nullptr, PT_EINVAL, "null context");
+	if (n && !inst) return fail(c, PT_EINVAL, "pt_set_instances: null array");
+	if (n > 0x0FFFFFF0u) return fail(c, PT_ELIMIT, "pt_set_instances: too many instances");
+	std::vector<float> v((size_t)n * 24);
+	for (uint32_t i = 0; i < n; ++i)
+	{
+		if (inst[i].custom_index != 0)
+			return fail(c, PT_EINVAL, "pt_set_instances: instance %u: custom_index %u (one Model only, as in the reference)", i,
+			            inst[i].custom_index);
+		const float *t = inst[i].transform;
+		for (int k = 0; k < 12; ++k)
+			if (!(fabsf(t[k]) <= 3.0e38f)) return fail(c, PT_EINVAL, "pt_set_instances: instance %u: non-finite transform", i);
+		// glm::inverse of the 4x4 (column-major m[c][r]) whose last row is (0,0,0,1): what gl_WorldToObjectEXT holds
+		float m[16], inv[16];
+		for (int col = 0; col < 4; ++col)
+		{
+			for (int r = 0; r < 3; ++r) m[4 * col + r] = t[4 * r + col];
+			m[4 * col + 3] = col == 3 ? 1.0f : 0.0f;
+		}
+		pt_inverse4(m, inv);
+		float *o = &v[(size_t)i * 24];
+		for (int k = 0; k < 12; ++k) o[k] = t[k];
+		for (int r = 0; r < 3; ++r)
+			for (int col = 0; col < 4; ++col)
+			{
+				float x = inv[4 * col + r];
+				if (!(fabsf(x) <= 3.0e38f)) return fail(c, PT_EINVAL, "pt_set_instances: instance %u: singular transform", i);
+				o[12 + 4 * r + col] = x;
+			}
+	}
+	c->instances.swap(v);
+	c->nInst = n;
+	c->haveAccel = false;  // the top-level structure must be rebuilt: pt_build_accel
+	c->frame = -1;
 	return PT_OK;
 }
 
@@ -503,6 +643,8 @@ extern "C" int pt_render_frame(pt_ctx *c)
 	const uint32_t WH = tile.w * tile.h;  // pixels this dispatch covers
 	const size_t nPaths = (size_t)WH * c->spp;
 	const bool persistent = (c->pipeline == PT_PIPELINE_PERSISTENT) && !c->brute;
+	if (c->nInst && !persistent)
+		return fail(c, PT_EINVAL, "pt_render_frame: instanced scenes run on PT_PIPELINE_PERSISTENT with a BVH only");
 	const size_t nPadded = (size_t)((WH + PT_WAVE - 1) / PT_WAVE) * PT_WAVE * c->spp;  // whole pixel groups of 64
 	if (nPadded > 0xFFFFFF00ull) return fail(c, PT_EINVAL, "pt_render_frame: %zu paths per frame exceed 2^32", nPadded);
 	rc = ensureQueues(c, persistent ? nPadded : nPaths);
@@ -566,6 +708,9 @@ extern "C" int pt_render_frame(pt_ctx *c)
 		pa.spill = c->cfg.spill;
 		pa.spillStride = c->cfg.spillStride;
 		pa.trav = trav;
+		pa.instances = c->dInstances;
+		pa.nInst = c->tlasDepth ? c->nInst : 0;
+		pa.tlasRoot = c->tlasRoot;
 		ptLaunchPaths(pa, c->cfg.bounceWaves, trav != nullptr, s);
 		if (e1) hipEventRecord(e1, s);
 		ptLaunchAccumulateItems(c->q.rad, tile, c->W, (uint32_t)c->spp, c->image, (uint32_t)c->frame, c->accumMode, s);

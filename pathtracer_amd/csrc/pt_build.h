@@ -11,6 +11,13 @@ struct PtBuildInput
 	uint32_t nTris;
 	int leafMax;  // triangles per leaf (1..PT_LEAF_MAX); 0 = PT_LEAF_DEFAULT
 	int builder;  // PT_BUILDER_LBVH (Karras topology + refit) or PT_BUILDER_PLOC (locally-ordered clustering)
+	// Box mode (top-level structure over instances): primitives are nTris axis-aligned boxes instead of
+	// triangles (vertices/indices unused), every leaf holds exactly one and its reference is PT_LEAF_FLAG | index,
+	// no triangle array is produced.  nodeBase is added to every inner-node reference (the caller places the
+	// nodes behind another tree in one array); padExp: boxes are padded by 2^-padExp * max|coordinate|.
+	const float4 *boxLo = nullptr, *boxHi = nullptr;
+	uint32_t nodeBase = 0;
+	int padExp = 18;
 };
 
 struct PtBuildOutput

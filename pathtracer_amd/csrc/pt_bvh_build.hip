@@ -111,6 +111,27 @@ __global__ void __launch_bounds__(kBlock) k_tri_setup(const PtVertex *verts, con
 	}
 }
 
+// Box mode: the primitive boxes are given; only the centroid bounds and max |coordinate| are reduced.
+__global__ void __launch_bounds__(kBlock) k_box_setup(const float4 *inLo, const float4 *inHi, uint32_t n, float4 *triLo,
+                                                      float4 *triHi, int *bounds)
+{
+	uint32_t i = blockIdx.x * kBlock + threadIdx.x;
+	if (i >= n) return;
+	float4 lo = inLo[i], hi = inHi[i];
+	triLo[i] = lo;
+	triHi[i] = hi;
+	float l[3] = { lo.x, lo.y, lo.z }, h[3] = { hi.x, hi.y, hi.z };
+	float amax = 0.0f;
+	for (int k = 0; k < 3; ++k)
+	{
+		float c = (l[k] + h[k]) * 0.5f;
+		atomicMin(&bounds[k], floatToOrdered(c));
+		atomicMax(&bounds[3 + k], floatToOrdered(c));
+		amax = fmaxf(amax, fmaxf(fabsf(l[k]), fabsf(h[k])));
+	}
+	atomicMax(reinterpret_cast<unsigned int *>(&bounds[6]), __float_as_uint(amax));
+}
+
 __device__ __forceinline__ uint32_t expandBits10(uint32_t v)
 {
 	v = (v * 0x00010001u) & 0xFF0000FFu;
@@ -326,11 +347,11 @@ __device__ __forceinline__ void loadBox(const float *src, float lo[3], float hi[
 
 __global__ void __launch_bounds__(kBlock) k_refit(const float4 *triLo, const float4 *triHi, const uint32_t *sortedPrim,
                                                   int n, const int2 *children, const int *parent, const int *bounds,
-                                                  float *boxes, unsigned int *arrive)
+                                                  float *boxes, unsigned int *arrive, float padScale)
 {
 	int k = blockIdx.x * kBlock + threadIdx.x;
 	if (k >= n) return;
-	const float pad = __uint_as_float((unsigned int)bounds[6]) * (1.0f / 262144.0f);  // 2^-18 * max|coord|
+	const float pad = __uint_as_float((unsigned int)bounds[6]) * padScale;  // 2^-18 * max|coord| for triangles
 	uint32_t prim = sortedPrim[k];
 	float4 l4 = triLo[prim], h4 = triHi[prim];
 	float lo[3] = { l4.x - pad, l4.y - pad, l4.z - pad }, hi[3] = { h4.x + pad, h4.y + pad, h4.z + pad };
@@ -374,7 +395,7 @@ __global__ void __launch_bounds__(kBlock)
     k_collapse_level(const CollapseTask *tasksIn, uint32_t nIn, CollapseTask *tasksOut, uint32_t *nOut, int n,
                      const int2 *children, const uint32_t *subCount, const float *boxes, const uint32_t *sortedPrim,
                      const PtVertex *verts, const uint32_t *indices, PtNode4 *nodes, uint32_t *nodeCount,
-                     PtTri48 *tris, uint32_t *triCount, int leafMax)
+                     PtTri48 *tris, uint32_t *triCount, int leafMax, uint32_t nodeBase)
 {
 	uint32_t ti = blockIdx.x * kBlock + threadIdx.x;
 	if (ti >= nIn) return;
@@ -497,6 +518,13 @@ __global__ void __launch_bounds__(kBlock)
 					dfs[dsp++] = ch.x;
 				}
 			}
+			if (!verts)
+			{
+				// box mode (leafMax == 1): the leaf reference is the primitive (instance) index itself
+				atomicAdd(triCount, 1u);
+				node.child[s] = PT_LEAF_FLAG | prims[0];
+				continue;
+			}
 			uint32_t base = atomicAdd(triCount, (uint32_t)cnt);
 			for (int t = 0; t < cnt; ++t)
 			{
@@ -526,7 +554,7 @@ __global__ void __launch_bounds__(kBlock)
 		else
 		{
 			uint32_t idx = atomicAdd(nodeCount, 1u);
-			node.child[s] = idx;
+			node.child[s] = idx + nodeBase;
 			uint32_t q = atomicAdd(nOut, 1u);
 			tasksOut[q].bvh2 = slot[s];
 			tasksOut[q].out = idx;
@@ -554,11 +582,12 @@ constexpr int kPlocRadius = 16;
 
 __global__ void __launch_bounds__(kBlock) k_ploc_leaves(const float4 *triLo, const float4 *triHi,
                                                         const uint32_t *sortedPrim, int n, const int *bounds,
-                                                        float *boxes, uint32_t *subCount, uint32_t *cluster)
+                                                        float *boxes, uint32_t *subCount, uint32_t *cluster,
+                                                        float padScale)
 {
 	int k = blockIdx.x * kBlock + threadIdx.x;
 	if (k >= n) return;
-	const float pad = __uint_as_float((unsigned int)bounds[6]) * (1.0f / 262144.0f);  // as k_refit
+	const float pad = __uint_as_float((unsigned int)bounds[6]) * padScale;  // as k_refit
 	uint32_t prim = sortedPrim[k];
 	float4 l4 = triLo[prim], h4 = triHi[prim];
 	float *b = boxes + 8 * (size_t)((n - 1) + k);
@@ -688,7 +717,9 @@ static inline uint32_t divUp(size_t a, size_t b) { return (uint32_t)((a + b - 1)
 hipError_t ptBuildBvh4(const PtBuildInput &in, PtBuildOutput &out, hipStream_t stream)
 {
 	const uint32_t n = in.nTris;
-	const int leafMax = in.leafMax < 1 ? PT_LEAF_DEFAULT : (in.leafMax > PT_LEAF_MAX ? PT_LEAF_MAX : in.leafMax);
+	const bool boxMode = in.boxLo != nullptr;
+	const int leafMax = boxMode ? 1 : (in.leafMax < 1 ? PT_LEAF_DEFAULT : (in.leafMax > PT_LEAF_MAX ? PT_LEAF_MAX : in.leafMax));
+	const float padScale = ldexpf(1.0f, -in.padExp);
 	out = PtBuildOutput();
 	if (n == 0) return hipSuccess;
 	if (n > 0x0FFFFFFFu) return hipErrorInvalidValue;
@@ -742,7 +773,7 @@ hipError_t ptBuildBvh4(const PtBuildInput &in, PtBuildOutput &out, hipStream_t s
 	PtTri48 *tris = nullptr;
 	uint32_t *codes = nullptr, *order = nullptr;
 	TRY(hipMalloc(&nodes, sizeof(PtNode4) * (size_t)n));  // a wide node has >= 2 children unless it is the root
-	TRY(hipMalloc(&tris, 3 * sizeof(PtTri48) * (size_t)n));  // three axis-rotated planes
+	if (!boxMode) TRY(hipMalloc(&tris, 3 * sizeof(PtTri48) * (size_t)n));  // three axis-rotated planes
 	TRY(hipMalloc(&codes, 4 * (size_t)n));
 	TRY(hipMalloc(&order, 4 * (size_t)n));
 
@@ -751,8 +782,10 @@ hipError_t ptBuildBvh4(const PtBuildInput &in, PtBuildOutput &out, hipStream_t s
 	{
 		const uint32_t gridTris = divUp(n, kBlock);
 		k_init_bounds<<<1, 64, 0, stream>>>(bounds);
-		k_tri_setup<<<gridTris < 2048 ? gridTris : 2048, kBlock, 0, stream>>>(in.vertices, in.indices, n, triLo, triHi,
-		                                                                       bounds);
+		if (boxMode) k_box_setup<<<gridTris, kBlock, 0, stream>>>(in.boxLo, in.boxHi, n, triLo, triHi, bounds);
+		else
+			k_tri_setup<<<gridTris < 2048 ? gridTris : 2048, kBlock, 0, stream>>>(in.vertices, in.indices, n, triLo, triHi,
+			                                                                       bounds);
 		k_morton<<<gridTris, kBlock, 0, stream>>>(triLo, triHi, n, bounds, codes, keysA, valsA);
 		uint32_t *kin = keysA, *kout = keysB, *vin = valsA, *vout = valsB;
 		for (int shift = 0; shift < 32; shift += 8)
@@ -775,12 +808,14 @@ hipError_t ptBuildBvh4(const PtBuildInput &in, PtBuildOutput &out, hipStream_t s
 			err = hipMemsetAsync(arrive, 0, sizeof(unsigned int) * n, stream);
 			if (n > 1) k_lbvh_topology<<<divUp(n - 1, kBlock), kBlock, 0, stream>>>(kin, (int)n, children, parent, range);
 			else TRY(hipMemsetAsync(parent, 0xFF, sizeof(int), stream));  // single leaf: parent = -1
-			k_refit<<<gridTris, kBlock, 0, stream>>>(triLo, triHi, vin, (int)n, children, parent, bounds, boxes, arrive);
+			k_refit<<<gridTris, kBlock, 0, stream>>>(triLo, triHi, vin, (int)n, children, parent, bounds, boxes, arrive,
+			                                         padScale);
 			k_lbvh_counts<<<gridTris, kBlock, 0, stream>>>(range, (int)n, subCount);
 		}
 		if (err == hipSuccess && ploc)
 		{
-			k_ploc_leaves<<<gridTris, kBlock, 0, stream>>>(triLo, triHi, vin, (int)n, bounds, boxes, subCount, clusterA);
+			k_ploc_leaves<<<gridTris, kBlock, 0, stream>>>(triLo, triHi, vin, (int)n, bounds, boxes, subCount, clusterA,
+			                                               padScale);
 			uint32_t m = n, created = 0;
 			uint32_t *cin = clusterA, *cout = clusterB;
 			while (err == hipSuccess && m > 1)
@@ -819,8 +854,9 @@ hipError_t ptBuildBvh4(const PtBuildInput &in, PtBuildOutput &out, hipStream_t s
 		{
 			++depth;
 			k_collapse_level<<<divUp(nIn, kBlock), kBlock, 0, stream>>>(tin, nIn, tout, counters + 2, (int)n, children,
-			                                                          subCount, boxes, vin, in.vertices, in.indices, nodes,
-			                                                          counters, tris, counters + 1, leafMax);
+			                                                          subCount, boxes, vin, boxMode ? nullptr : in.vertices,
+			                                                          in.indices, nodes, counters, tris, counters + 1,
+			                                                          leafMax, in.nodeBase);
 			uint32_t h[4];
 			err = hipMemcpyAsync(h, counters, sizeof(h), hipMemcpyDeviceToHost, stream);
 			TRY(hipStreamSynchronize(stream));

@@ -253,6 +253,8 @@ static_assert(sizeof(PtNode4) == 64, "PtNode4 must be 64 bytes");
 #define PT_LEAF_FLAG 0x80000000u
 #define PT_EMPTY_CHILD 0xFFFFFFFEu  // unused child slot (never reported as hit)
 #define PT_TRAVERSAL_DONE 0xFFFFFFFFu
+#define PT_INSTANCE_END 0xFFFFFFFDu  // stack marker: the bottom-level traversal of an instance is finished
+#define PT_NO_INSTANCE 0xFFFFFFFFu   // lane is traversing the top-level structure
 #define PT_LEAF_MAX 8      // the leaf reference has 3 bits for (count - 1)
 #define PT_LEAF_DEFAULT 2
 
@@ -281,8 +283,12 @@ struct PtSceneDev
 
 // ---------------------------------------------------------------------- closest hit ----
 // raytrace.rchit:24-59 for one hit.  Returns the new ray, updates seed; mat = material record.
+// xf != nullptr: the hit lies in an instance with xf = object-to-world 3x4 followed by world-to-object 3x4 (both
+// row-major): rchit:45-46 -- worldHitPos = vec3(gl_ObjectToWorldEXT * vec4(localHitPos, 1)) in glm's association
+// (c0*x + c1*y) + (c2*z + c3*1); worldHitNormal = normalize(vec3(localHitNormal * gl_WorldToObjectEXT)), a row
+// vector times the matrix.  xf == nullptr is the reference's single identity instance (no transform arithmetic).
 __device__ __forceinline__ void pt_shade_hit(const PtSceneDev &sc, uint32_t prim, float u, float v, uint32_t &seed,
-                                         float3x &o, float3x &d, const float *&mat)
+                                         float3x &o, float3x &d, const float *&mat, const float *xf = nullptr)
 {
 	mat = sc.materials[sc.matIndices[prim]].diffuse;
 	const float *v0 = sc.vertices[sc.indices[3 * (size_t)prim + 0]].pos;
@@ -296,6 +302,19 @@ __device__ __forceinline__ void pt_shade_hit(const PtSceneDev &sc, uint32_t prim
 	P.x = (v0[0] * bx + v1[0] * by) + v2[0] * bz;
 	P.y = (v0[1] * bx + v1[1] * by) + v2[1] * bz;
 	P.z = (v0[2] * bx + v1[2] * by) + v2[2] * bz;
+	if (xf)
+	{
+		const float *w = xf + 12;
+		float3x Pw, Nw;
+		Pw.x = (xf[0] * P.x + xf[1] * P.y) + (xf[2] * P.z + xf[3] * 1.0f);
+		Pw.y = (xf[4] * P.x + xf[5] * P.y) + (xf[6] * P.z + xf[7] * 1.0f);
+		Pw.z = (xf[8] * P.x + xf[9] * P.y) + (xf[10] * P.z + xf[11] * 1.0f);
+		Nw.x = (N.x * w[0] + N.y * w[4]) + N.z * w[8];
+		Nw.y = (N.x * w[1] + N.y * w[5]) + N.z * w[9];
+		Nw.z = (N.x * w[2] + N.y * w[6]) + N.z * w[10];
+		P = Pw;
+		N = Nw;
+	}
 	float3x Nn = pt_normalize(N);
 	float3x rv = pt_rnd_unit_vector(seed);
 	d = pt_normalize({ Nn.x + rv.x, Nn.y + rv.y, Nn.z + rv.z });

@@ -38,20 +38,26 @@
 namespace
 {
 constexpr int kStackLds = 12;   // traversal stack entries per lane held in LDS; deeper ones spill to global
-constexpr int kInFields = 11;   // ox oy oz ix iy iz Sx Sy Sz kpack(kz | signs | depth << 16) q
-constexpr int kDoneFields = 6;  // V W det prim q kpack
+constexpr int kInFields = 11;   // ox oy oz ix iy iz Sx Sy Sz kpack(kz | signs | depth << 16) q   (+ dx dy dz: two-level)
+constexpr int kDoneFields = 6;  // V W det prim q kpack                                          (+ instance: two-level)
+constexpr int kSaveFields = 7;  // two-level: prepared world ray (ix iy iz Sx Sy Sz kpack) while a lane is inside an instance
 constexpr int kDoneRing = 128;
 constexpr uint32_t kRefillLanes = PT_REFILL_LANES;
 constexpr uint32_t kNoPath = 0xFFFFFFFFu;
 
 __device__ __forceinline__ uint32_t popc64(unsigned long long m) { return (uint32_t)__popcll(m); }
 
-template <bool kStats>
+// kInst: two-level scene (pt_set_instances).  A lane starts in the top-level tree (inst == PT_NO_INSTANCE), where
+// a leaf reference is an instance index: the lane saves its prepared world ray in LDS, transforms the ray with the
+// instance's world-to-object matrix (direction NOT renormalised: t means the same in both spaces), pushes
+// PT_INSTANCE_END and descends into the bottom-level tree; popping the marker restores the world ray.
+template <bool kStats, bool kInst>
 __global__ void __launch_bounds__(PT_WAVE) k_paths(PtPathsArgs a)
 {
 	__shared__ uint32_t sStack[kStackLds][PT_WAVE];
-	__shared__ uint32_t sIn[kInFields][PT_WAVE];
-	__shared__ uint32_t sDone[kDoneFields][kDoneRing];
+	__shared__ uint32_t sIn[kInFields + (kInst ? 3 : 0)][PT_WAVE];
+	__shared__ uint32_t sDone[kDoneFields + (kInst ? 1 : 0)][kDoneRing];
+	__shared__ uint32_t sSave[kInst ? kSaveFields : 1][PT_WAVE];
 
 	const PtSceneDev &sc = a.sc;
 	const int lane = threadIdx.x;
@@ -83,6 +89,8 @@ __global__ void __launch_bounds__(PT_WAVE) k_paths(PtPathsArgs a)
 	// per-lane ray state
 	float ox = 0, oy = 0, oz = 0, ix = 0, iy = 0, iz = 0, Sx = 0, Sy = 0, Sz = 0;
 	uint32_t kpack = 0, q = kNoPath;
+	float wox = 0, woy = 0, woz = 0, wdx = 0, wdy = 0, wdz = 0;  // world ray (two-level scenes)
+	uint32_t inst = PT_NO_INSTANCE, bestInst = 0;
 	PtBest best = { tmax, PT_NO_HIT, 0.0f, 0.0f, 1.0f };
 	uint32_t cur = PT_TRAVERSAL_DONE;
 	int sp = 0;
@@ -105,7 +113,8 @@ __global__ void __launch_bounds__(PT_WAVE) k_paths(PtPathsArgs a)
 				float4 T = a.state[pq];  // throughput, rng state
 				uint32_t seed = __float_as_uint(T.w);
 				const float *mat;
-				pt_shade_hit(sc, prim, u, v, seed, no, nd, mat);
+				pt_shade_hit(sc, prim, u, v, seed, no, nd, mat,
+				             kInst ? a.instances + 24 * (size_t)sDone[kDoneFields][e] : nullptr);
 				float ex = mat[3], ey = mat[4], ez = mat[5];
 				if (ex != 0.0f || ey != 0.0f || ez != 0.0f)
 				{
@@ -147,6 +156,12 @@ __global__ void __launch_bounds__(PT_WAVE) k_paths(PtPathsArgs a)
 		sIn[8][lane] = __float_as_uint(pr.Sz);
 		sIn[9][lane] = pr.kpack | (depth << 16);
 		sIn[10][lane] = pq;
+		if (kInst)
+		{
+			sIn[kInFields + 0][lane] = __float_as_uint(d.x);
+			sIn[kInFields + 1][lane] = __float_as_uint(d.y);
+			sIn[kInFields + 2][lane] = __float_as_uint(d.z);
+		}
 	};
 
 	for (;;)
@@ -170,6 +185,7 @@ __global__ void __launch_bounds__(PT_WAVE) k_paths(PtPathsArgs a)
 					sDone[3][e] = best.prim;
 					sDone[4][e] = q;
 					sDone[5][e] = kpack;
+					if (kInst) sDone[kDoneFields][e] = bestInst;
 					q = kNoPath;
 				}
 				doneTail += popc64(fm);
@@ -309,6 +325,17 @@ __global__ void __launch_bounds__(PT_WAVE) k_paths(PtPathsArgs a)
 					Sz = __uint_as_float(sIn[8][s]);
 					kpack = sIn[9][s];
 					q = sIn[10][s];
+					if (kInst)
+					{
+						wox = ox;
+						woy = oy;
+						woz = oz;
+						wdx = __uint_as_float(sIn[kInFields + 0][s]);
+						wdy = __uint_as_float(sIn[kInFields + 1][s]);
+						wdz = __uint_as_float(sIn[kInFields + 2][s]);
+						inst = PT_NO_INSTANCE;
+						bestInst = 0;
+					}
 					best.t = tmax;
 					best.prim = PT_NO_HIT;
 					best.V = 0.0f;
@@ -316,7 +343,7 @@ __global__ void __launch_bounds__(PT_WAVE) k_paths(PtPathsArgs a)
 					best.det = 1.0f;
 					sStack[0][lane] = PT_TRAVERSAL_DONE;  // sentinel: popping an empty stack ends the traversal
 					sp = 1;
-					cur = sc.nNodes ? 0u : PT_TRAVERSAL_DONE;
+					cur = sc.nNodes ? (kInst ? a.tlasRoot : 0u) : PT_TRAVERSAL_DONE;
 				}
 				inPos += n;
 				idle &= ~__ballot(take);
@@ -355,8 +382,68 @@ __global__ void __launch_bounds__(PT_WAVE) k_paths(PtPathsArgs a)
 		}
 		if (!doNode && (cur & PT_LEAF_FLAG) && cur != PT_TRAVERSAL_DONE)
 		{
-			if (kStats && cur != PT_EMPTY_CHILD) ++leafVisits;
-			pt_leaf_step<kStackLds>(sc, ray, tmin, best, cur, sp, sStack, lane, mySpill, a.spillStride, triTests);
+			if (kInst && cur == PT_INSTANCE_END)
+			{
+				// bottom-level traversal finished: back to the world ray and the top-level tree
+				ox = wox;
+				oy = woy;
+				oz = woz;
+				ix = __uint_as_float(sSave[0][lane]);
+				iy = __uint_as_float(sSave[1][lane]);
+				iz = __uint_as_float(sSave[2][lane]);
+				Sx = __uint_as_float(sSave[3][lane]);
+				Sy = __uint_as_float(sSave[4][lane]);
+				Sz = __uint_as_float(sSave[5][lane]);
+				kpack = sSave[6][lane];
+				inst = PT_NO_INSTANCE;
+				cur = pt_stack_pop<kStackLds>(sp, sStack, lane, mySpill, a.spillStride);
+			}
+			else if (kInst && inst == PT_NO_INSTANCE)
+			{
+				if (cur == PT_EMPTY_CHILD) cur = pt_stack_pop<kStackLds>(sp, sStack, lane, mySpill, a.spillStride);
+				else
+				{
+					// top-level leaf = instance: ray into object space, o' = W2O * (o,1), d' = W2O * (d,0), each row
+					// ((m0*x + m1*y) + m2*z) + m3 -- then the same preparation as in the staging phase
+					inst = cur & 0x0FFFFFFFu;
+					const float4 *w = reinterpret_cast<const float4 *>(a.instances + 24 * (size_t)inst + 12);
+					const float4 r0 = w[0], r1 = w[1], r2 = w[2];
+					float3x oo, od;
+					oo.x = ((r0.x * wox + r0.y * woy) + r0.z * woz) + r0.w;
+					oo.y = ((r1.x * wox + r1.y * woy) + r1.z * woz) + r1.w;
+					oo.z = ((r2.x * wox + r2.y * woy) + r2.z * woz) + r2.w;
+					od.x = (r0.x * wdx + r0.y * wdy) + r0.z * wdz;
+					od.y = (r1.x * wdx + r1.y * wdy) + r1.z * wdz;
+					od.z = (r2.x * wdx + r2.y * wdy) + r2.z * wdz;
+					sSave[0][lane] = __float_as_uint(ix);
+					sSave[1][lane] = __float_as_uint(iy);
+					sSave[2][lane] = __float_as_uint(iz);
+					sSave[3][lane] = __float_as_uint(Sx);
+					sSave[4][lane] = __float_as_uint(Sy);
+					sSave[5][lane] = __float_as_uint(Sz);
+					sSave[6][lane] = kpack;
+					const PtLaneRay pr = pt_prepare_ray(oo, od);
+					ox = pr.ox;
+					oy = pr.oy;
+					oz = pr.oz;
+					ix = pr.ix;
+					iy = pr.iy;
+					iz = pr.iz;
+					Sx = pr.Sx;
+					Sy = pr.Sy;
+					Sz = pr.Sz;
+					kpack = pr.kpack | (kpack & 0xFFFF0000u);  // keep the depth bits
+					pt_stack_push<kStackLds>(PT_INSTANCE_END, sp, sStack, lane, mySpill, a.spillStride);
+					cur = 0u;  // bottom-level root
+					if (kStats) ++leafVisits;
+				}
+			}
+			else
+			{
+				if (kStats && cur != PT_EMPTY_CHILD) ++leafVisits;
+				pt_leaf_step<kStackLds>(sc, ray, tmin, best, cur, sp, sStack, lane, mySpill, a.spillStride, triTests,
+				                        kInst ? inst : 0u, kInst ? &bestInst : nullptr);
+			}
 		}
 	}
 
@@ -422,8 +509,16 @@ __global__ void __launch_bounds__(256)
 
 void ptLaunchPaths(const PtPathsArgs &args, uint32_t waves, bool stats, hipStream_t s)
 {
-	if (stats) k_paths<true><<<waves, PT_WAVE, 0, s>>>(args);
-	else k_paths<false><<<waves, PT_WAVE, 0, s>>>(args);
+	if (args.nInst)
+	{
+		if (stats) k_paths<true, true><<<waves, PT_WAVE, 0, s>>>(args);
+		else k_paths<false, true><<<waves, PT_WAVE, 0, s>>>(args);
+	}
+	else
+	{
+		if (stats) k_paths<true, false><<<waves, PT_WAVE, 0, s>>>(args);
+		else k_paths<false, false><<<waves, PT_WAVE, 0, s>>>(args);
+	}
 }
 
 void ptLaunchAccumulateItems(const float4 *rad, PtTile tile, uint32_t W, uint32_t spp, float4 *image, uint32_t lframe,

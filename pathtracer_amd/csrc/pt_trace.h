@@ -4,6 +4,7 @@
 
 #define PT_MAX_DEPTH 64     // upper bound for max_depth (reference: 20)
 #define PT_SPILL_STACK 72   // traversal stack entries per lane beyond the LDS-resident ones
+#define PT_STACK_CAPACITY (12 + PT_SPILL_STACK)  // smallest traversal stack of any kernel: LDS entries + spill
 #define PT_CHUNK 1024u      // queue records per chunk (work-claim and compaction granularity)
 
 // Sub-rectangle of the image a dispatch covers (pt_set_tile; default = the whole image).  Tile pixel t maps to
@@ -78,6 +79,10 @@ struct PtPathsArgs
 	uint32_t *spill;
 	uint32_t spillStride;
 	unsigned long long *trav;  // traversal statistics (stats variant only)
+	// two-level scenes (pt_set_instances): 24 floats per instance (object-to-world 3x4, world-to-object 3x4, row-major);
+	// sc.nodes holds the bottom-level tree at index 0 and the top-level tree at tlasRoot; nInst == 0: single level
+	const float *instances;
+	uint32_t nInst, tlasRoot;
 };
 void ptLaunchPaths(const PtPathsArgs &args, uint32_t waves, bool stats, hipStream_t s);
 void ptLaunchAccumulateItems(const float4 *rad, PtTile tile, uint32_t W, uint32_t spp, float4 *image, uint32_t lframe, int mode,

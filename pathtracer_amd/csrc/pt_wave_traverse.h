@@ -143,9 +143,31 @@ __device__ __forceinline__ void pt_node_step(const PtSceneDev &sc, const PtLaneR
 }
 
 template <int kStackLds>
+__device__ __forceinline__ uint32_t pt_stack_pop(int &sp, uint32_t (*sStack)[PT_WAVE], int lane, uint32_t *mySpill,
+                                                 uint32_t spillStride)
+{
+	--sp;
+	return sp < kStackLds ? sStack[sp][lane]
+	                      : (sp < kStackLds + PT_SPILL_STACK ? mySpill[(size_t)(sp - kStackLds) * spillStride]
+	                                                         : PT_EMPTY_CHILD);
+}
+
+template <int kStackLds>
+__device__ __forceinline__ void pt_stack_push(uint32_t v, int &sp, uint32_t (*sStack)[PT_WAVE], int lane,
+                                              uint32_t *mySpill, uint32_t spillStride)
+{
+	if (sp < kStackLds) sStack[sp][lane] = v;
+	else if (sp < kStackLds + PT_SPILL_STACK) mySpill[(size_t)(sp - kStackLds) * spillStride] = v;
+	++sp;
+}
+
+// curInst / bestInst: instance the lane is inside and instance of the best hit (two-level scenes; ties at equal t
+// go to the lower instance index, then the lower primitive id).  Single-level callers pass 0 and a dummy.
+template <int kStackLds>
 __device__ __forceinline__ void pt_leaf_step(const PtSceneDev &sc, const PtLaneRay &ray, float tmin, PtBest &best,
                                              uint32_t &cur, int &sp, uint32_t (*sStack)[PT_WAVE], int lane,
-                                             uint32_t *mySpill, uint32_t spillStride, uint32_t &triTests)
+                                             uint32_t *mySpill, uint32_t spillStride, uint32_t &triTests,
+                                             uint32_t curInst = 0u, uint32_t *bestInst = nullptr)
 {
 	const float ox = ray.ox, oy = ray.oy, oz = ray.oz, Sx = ray.Sx, Sy = ray.Sy, Sz = ray.Sz;
 	const uint32_t kpack = ray.kpack;
@@ -192,8 +214,12 @@ __device__ __forceinline__ void pt_leaf_step(const PtSceneDev &sc, const PtLaneR
 				float T = (U * Az + V * Bz) + W * Cz;
 				float t = T / det;
 				uint32_t prim = __float_as_uint(c.y);
-				if (t > tmin && (t < best.t || (t == best.t && best.prim != PT_NO_HIT && prim < best.prim)))
+				bool tie = t == best.t && best.prim != PT_NO_HIT;
+				if (bestInst) tie = tie && (curInst < *bestInst || (curInst == *bestInst && prim < best.prim));
+				else tie = tie && prim < best.prim;
+				if (t > tmin && (t < best.t || tie))
 				{
+					if (bestInst) *bestInst = curInst;
 					best.t = t;
 					best.prim = prim;
 					best.V = V;
