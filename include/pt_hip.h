@@ -60,7 +60,7 @@ typedef struct PtHit
 typedef struct PtStats
 {
 	uint64_t rays_total;        /* closest-hit queries since the last reset (one per traceRayEXT) */
-	uint64_t rays_last_frame;
+	uint64_t rays_last_frame;   /* mean over the frames of the most recent launch (several frames per launch) */
 	uint64_t paths_last_frame;  /* W*H*spp_per_frame */
 	uint64_t frames_rendered;
 	double extend_ms_total;     /* HIP-event time of the traversal kernels (only with PT_PROFILE_KERNELS) */

@@ -69,6 +69,11 @@ struct pt_ctx
 	PtLaunchCfg cfg = {};
 	uint2 *dLcgSkip = nullptr;  // persistent pipeline: LCG skip-ahead pairs for 0, 2, 4, .. steps
 	int lcgSkipSpp = 0;
+	float4 *pState = nullptr, *pRad = nullptr, *pRingO = nullptr, *pRingD = nullptr;
+	size_t pCap = 0;                        // records in pState / pRad
+	uint32_t lastLaunchFrames = 1;          // frames the most recent launch covered
+	int framesPerLaunch = 8;                // PT_FRAMES_PER_LAUNCH
+	size_t persistentBytes = 24ull << 30;   // budget for pState + pRad (PT_PERSISTENT_GB)
 
 	int profiling = 0;
 	std::vector<EventPair> pending;
@@ -286,6 +291,16 @@ extern "C" pt_ctx *pt_create(int device)
 		if (v >= 1 && v <= 16) wavesPerCU = v;
 	}
 	c->cfg.bounceWaves = (uint32_t)c->numCUs * (uint32_t)wavesPerCU;
+	if (const char *e = getenv("PT_FRAMES_PER_LAUNCH"))
+	{
+		int v = atoi(e);
+		if (v >= 1 && v <= 256) c->framesPerLaunch = v;
+	}
+	if (const char *e = getenv("PT_PERSISTENT_GB"))
+	{
+		int v = atoi(e);
+		if (v >= 1 && v <= 256) c->persistentBytes = (size_t)v << 30;
+	}
 	c->cfg.spillStride = c->cfg.persistentBlocks * 256u;
 	if (c->cfg.bounceWaves * 64u > c->cfg.spillStride) c->cfg.spillStride = c->cfg.bounceWaves * 64u;
 	ok = ok && hipMalloc(&c->cfg.waveRays, sizeof(uint32_t) * c->cfg.bounceWaves) == hipSuccess;
@@ -315,6 +330,10 @@ extern "C" void pt_destroy(pt_ctx *c)
 	hipFree(c->cfg.spill);
 	hipFree(c->cfg.waveRays);
 	hipFree(c->dLcgSkip);
+	hipFree(c->pState);
+	hipFree(c->pRad);
+	hipFree(c->pRingO);
+	hipFree(c->pRingD);
 	if (c->ownStream) hipStreamDestroy(c->ownStream);
 	delete c;
 }
@@ -632,52 +651,83 @@ extern "C" int pt_set_accum_mode(pt_ctx *c, int mode)
 	return PT_OK;
 }
 
-extern "C" int pt_render_frame(pt_ctx *c)
+namespace
 {
-	int rc = checkReady(c, true);
-	if (rc) return rc;
-	c->frame++;  // updateFrame()
-	if (c->maxFrames > 0 && c->frame >= c->maxFrames) return PT_OK;  // "Max frames reached"
-	PT_HIP(c, hipSetDevice(c->device));
-	const PtTile tile = c->tile.w ? c->tile : PtTile{ 0, 0, c->W, c->H };
-	const uint32_t WH = tile.w * tile.h;  // pixels this dispatch covers
-	const size_t nPaths = (size_t)WH * c->spp;
-	const bool persistent = (c->pipeline == PT_PIPELINE_PERSISTENT) && !c->brute;
-	if (c->nInst && !persistent)
-		return fail(c, PT_EINVAL, "pt_render_frame: instanced scenes run on PT_PIPELINE_PERSISTENT with a BVH only");
-	const size_t nPadded = (size_t)((WH + PT_WAVE - 1) / PT_WAVE) * PT_WAVE * c->spp;  // whole pixel groups of 64
-	if (nPadded > 0xFFFFFF00ull) return fail(c, PT_EINVAL, "pt_render_frame: %zu paths per frame exceed 2^32", nPadded);
-	rc = ensureQueues(c, persistent ? nPadded : nPaths);
-	if (rc) return rc;
-	if (persistent && c->lcgSkipSpp != c->spp)
+int ensureLcgSkip(pt_ctx *c)
+{
+	if (c->lcgSkipSpp == c->spp) return PT_OK;
+	// lcg^(2i)(s) = A_i * s + C_i (mod 2^32): lets a wave enter a pixel's seed chain at sample i (rgen:28-37)
+	std::vector<uint2> tab((size_t)c->spp);
+	uint32_t A = 1u, C = 0u;
+	for (int i = 0; i < c->spp; ++i)
 	{
-		// lcg^(2i)(s) = A_i * s + C_i (mod 2^32): lets a wave enter a pixel's seed chain at sample i (rgen:28-37)
-		std::vector<uint2> tab((size_t)c->spp);
-		uint32_t A = 1u, C = 0u;
-		for (int i = 0; i < c->spp; ++i)
+		tab[(size_t)i] = make_uint2(A, C);
+		for (int k = 0; k < 2; ++k)
 		{
-			tab[(size_t)i] = make_uint2(A, C);
-			for (int k = 0; k < 2; ++k)
-			{
-				A = 1664525u * A;
-				C = 1664525u * C + 1013904223u;
-			}
+			A = 1664525u * A;
+			C = 1664525u * C + 1013904223u;
 		}
-		PT_HIP(c, hipStreamSynchronize(c->stream));  // frames in flight still read the old table
-		hipFree(c->dLcgSkip);
-		c->dLcgSkip = nullptr;
-		PT_HIP(c, hipMalloc(&c->dLcgSkip, sizeof(uint2) * tab.size()));
-		PT_HIP(c, hipMemcpy(c->dLcgSkip, tab.data(), sizeof(uint2) * tab.size(), hipMemcpyHostToDevice));
-		c->lcgSkipSpp = c->spp;
 	}
-	const uint32_t gframe = c->firstFrame + (uint32_t)c->frame * c->frameStride;
+	PT_HIP(c, hipStreamSynchronize(c->stream));  // frames in flight still read the old table
+	hipFree(c->dLcgSkip);
+	c->dLcgSkip = nullptr;
+	PT_HIP(c, hipMalloc(&c->dLcgSkip, sizeof(uint2) * tab.size()));
+	PT_HIP(c, hipMemcpy(c->dLcgSkip, tab.data(), sizeof(uint2) * tab.size(), hipMemcpyHostToDevice));
+	c->lcgSkipSpp = c->spp;
+	return PT_OK;
+}
+
+// Buffers of the persistent pipeline: per-path state and radiance for every frame of a launch, wave-private rings.
+int ensurePersistent(pt_ctx *c, size_t records)
+{
+	if (records > c->pCap)
+	{
+		PT_HIP(c, hipStreamSynchronize(c->stream));
+		hipFree(c->pState);
+		hipFree(c->pRad);
+		c->pState = c->pRad = nullptr;
+		c->pCap = 0;
+		PT_HIP(c, hipMalloc(&c->pState, records * sizeof(float4)));
+		PT_HIP(c, hipMalloc(&c->pRad, records * sizeof(float4)));
+		c->pCap = records;
+	}
+	if (!c->pRingO)
+	{
+		const size_t ring = (size_t)c->cfg.bounceWaves * PT_PATHS_RING * sizeof(float4);
+		PT_HIP(c, hipMalloc(&c->pRingO, ring));
+		PT_HIP(c, hipMalloc(&c->pRingD, ring));
+	}
+	return PT_OK;
+}
+
+// `n` consecutive active frames (c->frame + 1 ...) on the persistent pipeline, several frames per launch.
+int renderPersistent(pt_ctx *c, int n)
+{
+	const PtTile tile = c->tile.w ? c->tile : PtTile{ 0, 0, c->W, c->H };
+	const uint32_t WH = tile.w * tile.h;  // pixels a dispatch covers
+	const size_t nPadded = (size_t)((WH + PT_WAVE - 1) / PT_WAVE) * PT_WAVE * c->spp;  // whole pixel groups of 64
+	// frames per launch: path ids q = item * 64 + lane stay below 2^32, state + radiance stay below the memory budget
+	size_t perLaunch = (size_t)c->framesPerLaunch;
+	if (perLaunch * nPadded > 0xFFFFFF00ull) perLaunch = 0xFFFFFF00ull / nPadded;
+	if (perLaunch * nPadded * 32 > c->persistentBytes) perLaunch = c->persistentBytes / (nPadded * 32);
+	if (perLaunch < 1) perLaunch = 1;
+	if (nPadded > 0xFFFFFF00ull) return fail(c, PT_EINVAL, "pt_render_frame: %zu paths per frame exceed 2^32", nPadded);
+	int rc = ensureLcgSkip(c);
+	if (rc) return rc;
 	hipStream_t s = c->stream;
 	PtSceneDev sc = sceneDev(c);
-	const bool fused = (c->pipeline == PT_PIPELINE_FUSED) && !c->brute;
 	unsigned long long *trav = (c->profiling & PT_PROFILE_TRAVERSAL) ? c->dStats + 2 : nullptr;
-	ptLaunchFrameBegin(c->counters, (uint32_t)nPaths, fused ? 1 : 0, s);
-	if (persistent)
+	while (n > 0)
 	{
+		const uint32_t batch = (uint32_t)((size_t)n < perLaunch ? (size_t)n : perLaunch);
+		rc = ensurePersistent(c, nPadded * batch);
+		if (rc) return rc;
+		const uint32_t frame0 = (uint32_t)(c->frame + 1);
+		const uint32_t gframe0 = c->firstFrame + frame0 * c->frameStride;
+		uint32_t centre = 0xFFFFFFFFu;
+		for (uint32_t f = 0; f < batch; ++f)
+			if (gframe0 + f * c->frameStride == 0) centre = f;
+		ptLaunchFrameBegin(c->counters, (uint32_t)0, 0, s);
 		hipEvent_t e0 = nullptr, e1 = nullptr, e2 = nullptr;
 		if (c->profiling & PT_PROFILE_KERNELS)
 		{
@@ -693,16 +743,18 @@ extern "C" int pt_render_frame(pt_ctx *c)
 		pa.H = c->H;
 		pa.tile = tile;
 		pa.spp = (uint32_t)c->spp;
-		pa.seedWord = c->seed + gframe;
-		pa.centreJitter = gframe == 0;
+		pa.seedWord = c->seed + gframe0;
+		pa.frameStride = c->frameStride;
+		pa.nFrames = batch;
+		pa.centreFrame = centre;
 		pa.maxDepth = c->maxDepth;
 		pa.tmin = c->tmin;
 		pa.tmax = c->tmax;
 		pa.lcgSkip = c->dLcgSkip;
-		pa.ringO = c->q.rayO[0];
-		pa.ringD = c->q.rayD[0];
-		pa.state = c->q.thr[0];
-		pa.rad = c->q.rad;
+		pa.ringO = c->pRingO;
+		pa.ringD = c->pRingD;
+		pa.state = c->pState;
+		pa.rad = c->pRad;
 		pa.itemHead = &c->counters->chunkHead[0];
 		pa.waveRays = c->cfg.waveRays;
 		pa.spill = c->cfg.spill;
@@ -713,7 +765,7 @@ extern "C" int pt_render_frame(pt_ctx *c)
 		pa.tlasRoot = c->tlasRoot;
 		ptLaunchPaths(pa, c->cfg.bounceWaves, trav != nullptr, s);
 		if (e1) hipEventRecord(e1, s);
-		ptLaunchAccumulateItems(c->q.rad, tile, c->W, (uint32_t)c->spp, c->image, (uint32_t)c->frame, c->accumMode, s);
+		ptLaunchAccumulateItems(c->pRad, tile, c->W, (uint32_t)c->spp, c->image, frame0, batch, c->accumMode, s);
 		if (e2)
 		{
 			hipEventRecord(e2, s);
@@ -721,9 +773,28 @@ extern "C" int pt_render_frame(pt_ctx *c)
 		}
 		ptLaunchFrameEnd(c->counters, 0, c->dStats, c->cfg.waveRays, c->cfg.bounceWaves, s);
 		PT_HIP(c, hipGetLastError());
-		c->framesRendered++;
-		return PT_OK;
+		c->frame += (int)batch;
+		c->framesRendered += batch;
+		c->lastLaunchFrames = batch;
+		n -= (int)batch;
 	}
+	return PT_OK;
+}
+
+// One frame (c->frame, already advanced) on the per-bounce pipelines.
+int renderClassic(pt_ctx *c)
+{
+	const PtTile tile = c->tile.w ? c->tile : PtTile{ 0, 0, c->W, c->H };
+	const uint32_t WH = tile.w * tile.h;
+	const size_t nPaths = (size_t)WH * c->spp;
+	int rc = ensureQueues(c, nPaths);
+	if (rc) return rc;
+	const uint32_t gframe = c->firstFrame + (uint32_t)c->frame * c->frameStride;
+	hipStream_t s = c->stream;
+	PtSceneDev sc = sceneDev(c);
+	const bool fused = (c->pipeline == PT_PIPELINE_FUSED) && !c->brute;
+	unsigned long long *trav = (c->profiling & PT_PROFILE_TRAVERSAL) ? c->dStats + 2 : nullptr;
+	ptLaunchFrameBegin(c->counters, (uint32_t)nPaths, fused ? 1 : 0, s);
 	ptLaunchGenerate(c->cam, c->W, c->H, tile, (uint32_t)c->spp, c->seed + gframe, gframe == 0, c->q, s);
 	int in = 0;
 	for (int d = 0; d < c->maxDepth; ++d)
@@ -761,24 +832,50 @@ extern "C" int pt_render_frame(pt_ctx *c)
 	ptLaunchFrameEnd(c->counters, c->maxDepth, c->dStats, c->cfg.waveRays, c->cfg.bounceWaves, s);
 	PT_HIP(c, hipGetLastError());
 	c->framesRendered++;
+	c->lastLaunchFrames = 1;
 	return PT_OK;
 }
+}  // namespace
+
+// VulkanRaytracing::raytrace, n times: the frame counter always advances (updateFrame); frames at or beyond
+// max_frames are no-ops ("Max frames reached", VulkanRaytracing.cpp:877-886).
+extern "C" int pt_render_frames(pt_ctx *c, int n)
+{
+	int rc = checkReady(c, true);
+	if (rc) return rc;
+	if (n <= 0) return PT_OK;
+	PT_HIP(c, hipSetDevice(c->device));
+	const bool persistent = (c->pipeline == PT_PIPELINE_PERSISTENT) && !c->brute;
+	if (c->nInst && !persistent)
+		return fail(c, PT_EINVAL, "pt_render_frame: instanced scenes run on PT_PIPELINE_PERSISTENT with a BVH only");
+	const long long next = (long long)c->frame + 1;
+	long long active = n;
+	if (c->maxFrames > 0) active = next >= c->maxFrames ? 0 : (c->maxFrames - next < n ? c->maxFrames - next : n);
+	if (persistent)
+	{
+		rc = renderPersistent(c, (int)active);
+		if (rc) return rc;
+	}
+	else
+	{
+		for (long long i = 0; i < active; ++i)
+		{
+			c->frame++;
+			rc = renderClassic(c);
+			if (rc) return rc;
+		}
+	}
+	c->frame += (int)(n - active);
+	return PT_OK;
+}
+
+extern "C" int pt_render_frame(pt_ctx *c) { return pt_render_frames(c, 1); }
 
 extern "C" int pt_set_pipeline(pt_ctx *c, int mode)
 {
 	if (!c) return fail(nullptr, PT_EINVAL, "null context");
 	if (mode != PT_PIPELINE_FUSED && mode != PT_PIPELINE_SPLIT && mode != PT_PIPELINE_PERSISTENT) return fail(c, PT_EINVAL, "pt_set_pipeline: bad mode %d", mode);
 	c->pipeline = mode;
-	return PT_OK;
-}
-
-extern "C" int pt_render_frames(pt_ctx *c, int n)
-{
-	for (int i = 0; i < n; ++i)
-	{
-		int rc = pt_render_frame(c);
-		if (rc) return rc;
-	}
 	return PT_OK;
 }
 
@@ -923,7 +1020,7 @@ extern "C" int pt_get_stats(pt_ctx *c, PtStats *out)
 	drainEvents(c);
 	memset(out, 0, sizeof(*out));
 	out->rays_total = h[0];
-	out->rays_last_frame = h[1];
+	out->rays_last_frame = h[1] / c->lastLaunchFrames;  // mean over the frames of the last launch
 	out->paths_last_frame = (c->tile.w ? (uint64_t)c->tile.w * c->tile.h : (uint64_t)c->W * c->H) * (uint64_t)c->spp;
 	out->frames_rendered = c->framesRendered;
 	out->extend_ms_total = c->extendMs;

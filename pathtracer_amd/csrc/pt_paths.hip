@@ -65,7 +65,8 @@ __global__ void __launch_bounds__(PT_WAVE) k_paths(PtPathsArgs a)
 	uint32_t *mySpill = a.spill + (size_t)blockIdx.x * PT_WAVE + lane;
 	const float tmin = a.tmin, tmax = a.tmax;
 	const uint32_t WH = a.tile.w * a.tile.h;  // pixels of the tile this dispatch covers
-	const uint32_t totalItems = ((WH + PT_WAVE - 1) / PT_WAVE) * a.spp;
+	const uint32_t itemsPerFrame = ((WH + PT_WAVE - 1) / PT_WAVE) * a.spp;
+	const uint32_t totalItems = itemsPerFrame * a.nFrames;
 
 	// ---- generator (wave-uniform cursors + the per-lane raygen seed chain) ----
 	const uint32_t firstShare = totalItems / (2u * gridDim.x);
@@ -256,7 +257,8 @@ __global__ void __launch_bounds__(PT_WAVE) k_paths(PtPathsArgs a)
 							needSeed = true;
 						}
 						const uint32_t item = itemCur++;
-						const uint32_t g = item / a.spp, i = item - g * a.spp;
+						const uint32_t f = item / itemsPerFrame, local = item - f * itemsPerFrame;  // frame of the launch
+						const uint32_t g = local / a.spp, i = local - g * a.spp;
 						if (needSeed || i == 0)
 						{
 							needSeed = false;
@@ -265,7 +267,7 @@ __global__ void __launch_bounds__(PT_WAVE) k_paths(PtPathsArgs a)
 							const uint32_t ty = p / a.tile.w;
 							genPy = a.tile.y0 + ty;
 							genPx = a.tile.x0 + (p - ty * a.tile.w);
-							genSeed = pt_tea(genPy * a.W + genPx, a.seedWord);  // rgen:28 with val1 = seed + global frame
+							genSeed = pt_tea(genPy * a.W + genPx, a.seedWord + f * a.frameStride);  // rgen:28, val1 = seed + global frame
 							if (i)
 							{
 								uint2 ac = a.lcgSkip[i];  // state after 2*i lcg steps = A * s + C
@@ -278,7 +280,8 @@ __global__ void __launch_bounds__(PT_WAVE) k_paths(PtPathsArgs a)
 						{
 							float r1 = pt_rnd(genSeed);
 							float r2 = pt_rnd(genSeed);
-							float jx = a.centreJitter ? 0.5f : r1, jy = a.centreJitter ? 0.5f : r2;
+							const bool centre = f == a.centreFrame;  // rgen:38: frame 0 samples the pixel centre
+							float jx = centre ? 0.5f : r1, jy = centre ? 0.5f : r2;
 							float3x o, d;
 							pt_camera_ray(a.cam, a.W, a.H, genPx, genPy, jx, jy, o, d);
 							uint32_t pq = item * PT_WAVE + lane;
@@ -474,33 +477,37 @@ __global__ void __launch_bounds__(PT_WAVE) k_paths(PtPathsArgs a)
 // k_accumulate for the item-major radiance layout of k_paths: q(t, i) = ((t / 64) * spp + i) * 64 + t % 64,
 // t = pixel index inside the tile.
 __global__ void __launch_bounds__(256)
-    k_accumulate_items(const float4 *rad, PtTile tile, uint32_t W, uint32_t spp, float4 *image, uint32_t lframe, int mode)
+    k_accumulate_items(const float4 *rad, PtTile tile, uint32_t W, uint32_t spp, float4 *image, uint32_t lframe0,
+                       uint32_t nFrames, int mode)
 {
 	uint32_t t = blockIdx.x * 256 + threadIdx.x;
-	if (t >= tile.w * tile.h) return;
+	const uint32_t WH = tile.w * tile.h;
+	if (t >= WH) return;
 	const uint32_t p = (tile.y0 + t / tile.w) * W + tile.x0 + t % tile.w;  // image pixel of tile pixel t
-	const size_t base = (size_t)(t / PT_WAVE) * spp * PT_WAVE + (t % PT_WAVE);
-	float ax = 0.0f, ay = 0.0f, az = 0.0f;
-	for (uint32_t i = 0; i < spp; ++i)
+	const size_t framePitch = (size_t)((WH + PT_WAVE - 1) / PT_WAVE) * spp * PT_WAVE;
+	size_t base = (size_t)(t / PT_WAVE) * spp * PT_WAVE + (t % PT_WAVE);
+	const float S = (float)spp;
+	float4 out = lframe0 ? image[p] : make_float4(0.0f, 0.0f, 0.0f, 1.0f);
+	// the frames of the launch one after the other, exactly as if each had been a dispatch of its own
+	for (uint32_t f = 0; f < nFrames; ++f, base += framePitch)
 	{
-		float4 L = rad[base + (size_t)i * PT_WAVE];
-		ax += L.x;
-		ay += L.y;
-		az += L.z;
-	}
-	float S = (float)spp;
-	float cx = ax / S, cy = ay / S, cz = az / S;
-	float4 out;
-	if (lframe == 0) out = make_float4(cx, cy, cz, 1.0f);
-	else
-	{
-		float4 old = image[p];
-		if (mode == PT_ACCUM_SUM) out = make_float4(old.x + cx, old.y + cy, old.z + cz, 1.0f);
+		float ax = 0.0f, ay = 0.0f, az = 0.0f;
+		for (uint32_t i = 0; i < spp; ++i)
+		{
+			float4 L = rad[base + (size_t)i * PT_WAVE];
+			ax += L.x;
+			ay += L.y;
+			az += L.z;
+		}
+		float cx = ax / S, cy = ay / S, cz = az / S;
+		const uint32_t lframe = lframe0 + f;
+		if (lframe == 0) out = make_float4(cx, cy, cz, 1.0f);
+		else if (mode == PT_ACCUM_SUM) out = make_float4(out.x + cx, out.y + cy, out.z + cz, 1.0f);
 		else
 		{
 			float al = 1.0f / (float)(lframe + 1);
 			float be = 1.0f - al;
-			out = make_float4(old.x * be + cx * al, old.y * be + cy * al, old.z * be + cz * al, 1.0f);  // mix(old,new,a)
+			out = make_float4(out.x * be + cx * al, out.y * be + cy * al, out.z * be + cz * al, 1.0f);  // mix(old,new,a)
 		}
 	}
 	image[p] = out;
@@ -521,8 +528,8 @@ void ptLaunchPaths(const PtPathsArgs &args, uint32_t waves, bool stats, hipStrea
 	}
 }
 
-void ptLaunchAccumulateItems(const float4 *rad, PtTile tile, uint32_t W, uint32_t spp, float4 *image, uint32_t lframe,
-                             int mode, hipStream_t s)
+void ptLaunchAccumulateItems(const float4 *rad, PtTile tile, uint32_t W, uint32_t spp, float4 *image, uint32_t lframe0,
+                             uint32_t nFrames, int mode, hipStream_t s)
 {
-	k_accumulate_items<<<(tile.w * tile.h + 255) / 256, 256, 0, s>>>(rad, tile, W, spp, image, lframe, mode);
+	k_accumulate_items<<<(tile.w * tile.h + 255) / 256, 256, 0, s>>>(rad, tile, W, spp, image, lframe0, nFrames, mode);
 }

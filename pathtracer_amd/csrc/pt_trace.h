@@ -61,16 +61,21 @@ void ptLaunchBounce(const PtSceneDev &sc, const PtQueues &q, int in, PtFrameCoun
                     hipStream_t s);
 // Persistent path kernel (pt_paths.hip): one launch traces every path of the frame from camera ray to
 // termination.  Buffers: ringO/ringD = waves * PT_PATHS_RING records (wave-private survivor rings), state and
-// rad = ceil(tile pixels/64) * 64 * spp records in item-major order q = ((t / 64) * spp + sample) * 64 + t % 64
+// rad = nFrames * ceil(tile pixels/64) * 64 * spp records in item-major order q = ((t / 64) * spp + sample) * 64 + t % 64
 // (t = pixel index inside the tile).
 #define PT_PATHS_RING 256u
 struct PtPathsArgs
 {
 	PtSceneDev sc;
 	PtCamera cam;
-	uint32_t W, H, spp, seedWord;
+	uint32_t W, H, spp;
+	// One launch renders nFrames consecutive frames of the schedule (the drain at the end of a launch -- waves
+	// finishing their last paths at low lane utilisation, ~0.3 ms -- is paid once per launch, not per frame):
+	// frame f of the launch seeds with seedWord + f * frameStride (rgen:28, val1 = seed + global frame) and uses
+	// the pixel-centre jitter iff f == centreFrame (global frame 0; 0xFFFFFFFF: none).
+	uint32_t seedWord, frameStride, nFrames, centreFrame;
 	PtTile tile;
-	int centreJitter, maxDepth;
+	int maxDepth;
 	float tmin, tmax;
 	const uint2 *lcgSkip;  // [spp]: (A, C) with lcg^(2i)(s) = A * s + C
 	float4 *ringO, *ringD, *state, *rad;
@@ -85,8 +90,8 @@ struct PtPathsArgs
 	uint32_t nInst, tlasRoot;
 };
 void ptLaunchPaths(const PtPathsArgs &args, uint32_t waves, bool stats, hipStream_t s);
-void ptLaunchAccumulateItems(const float4 *rad, PtTile tile, uint32_t W, uint32_t spp, float4 *image, uint32_t lframe, int mode,
-                             hipStream_t s);
+void ptLaunchAccumulateItems(const float4 *rad, PtTile tile, uint32_t W, uint32_t spp, float4 *image, uint32_t lframe0,
+                             uint32_t nFrames, int mode, hipStream_t s);
 void ptLaunchAccumulate(const PtQueues &q, PtTile tile, uint32_t W, uint32_t spp, float4 *image, uint32_t lframe, int mode,
                         hipStream_t s);
 void ptLaunchDebugRng(uint32_t n, const uint32_t *v0, const uint32_t *v1, uint32_t nSteps, uint32_t *outTea,

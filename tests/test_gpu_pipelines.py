@@ -147,3 +147,31 @@ def test_tiles_reproduce_the_full_image(rt, pa, cornell, ocornell, pipeline):
     rt.resetFrame()
     rt.raytrace(2)
     assert np.array_equal(bits(rt.readImage()), bits(want))
+
+
+def test_many_frames_per_launch_equal_frame_by_frame(rt, pa, cornell, ocornell):
+    """pt_render_frames(n) puts up to PT_FRAMES_PER_LAUNCH (8) frames into one launch of the persistent kernel:
+    19 frames in one call (launches of 8 + 8 + 3) == 19 single-frame calls == the oracle, bit for bit; the
+    max_frames cut-off may fall inside a launch."""
+    W, H = 50, 21
+    view, proj = pa.reference_camera(W, H)
+    rt.buildBlas(cornell)
+    rt.resize(W, H)
+    rt.setCamera(view, proj)
+    rt.setParams(spp_per_frame=2, max_depth=6, seed=5, max_frames=0)
+    rt.raytrace(19)
+    assert rt.frame == 18
+    a, rays_a = rt.readImage(), rt.stats().rays_total
+    want, rays = ocornell.render(view, proj, W, H, frames=19, spp_per_frame=2, max_depth=6, seed=5)
+    assert rays_a == rays and np.array_equal(bits(a), bits(want))
+    rt.resetFrame()
+    rt.resetStats()
+    for _ in range(19):
+        rt.raytrace(1)
+    assert rt.stats().rays_total == rays and np.array_equal(bits(rt.readImage()), bits(want))
+    rt.setParams(spp_per_frame=2, max_depth=6, seed=5, max_frames=11)  # frames 0..10 render, the rest are no-ops
+    rt.resetFrame()
+    rt.raytrace(19)
+    assert rt.frame == 18
+    want11, _ = ocornell.render(view, proj, W, H, frames=11, spp_per_frame=2, max_depth=6, seed=5)
+    assert np.array_equal(bits(rt.readImage()), bits(want11))
