@@ -190,31 +190,110 @@ __global__ void __launch_bounds__(kBlock) k_radix_hist(const uint32_t *keys, uin
 	hist[(size_t)threadIdx.x * nBlocks + blockIdx.x] = bins[threadIdx.x];
 }
 
-// Exclusive scan of `len` counters, one block of 1024 threads: serial segment sums, a block scan
-// of the 1024 partials, serial write-back.
-__global__ void __launch_bounds__(1024) k_exclusive_scan(uint32_t *data, size_t len)
+// ------------------------------------------------------------------------- scan ----
+// Exclusive scan of `len` counters of type T (uint32_t, or two packed 32-bit counts in a uint64_t), any length:
+// tiles of 4096 (256 threads x 16 consecutive items); k_scan_reduce writes one sum per tile, the sums are scanned
+// by the same routine (recursion on the host: 100 M -> 24 K -> 6), k_scan_apply rescans each tile in LDS-free wave
+// arithmetic with the tile's offset.  HBM traffic 3 x sizeof(T) per item (read, read, write).
+constexpr int kScanItems = 16;
+constexpr int kScanTile = kBlock * kScanItems;
+
+template <typename T> __device__ __forceinline__ T waveInclusiveScan(T v, int lane)
 {
-	__shared__ uint32_t part[1024];
-	size_t per = (len + 1023) / 1024;
-	size_t b = (size_t)threadIdx.x * per, e = b + per < len ? b + per : len;
-	uint32_t s = 0;
-	for (size_t i = b; i < e; ++i) s += data[i];
-	part[threadIdx.x] = s;
+#pragma unroll
+	for (int o = 1; o < PT_WAVE; o <<= 1)
+	{
+		T u = __shfl_up(v, o);
+		if (lane >= o) v += u;
+	}
+	return v;
+}
+
+// Exclusive scan of one value per thread across the block (kBlock threads); total = sum over the block.
+template <typename T> __device__ __forceinline__ T blockExclusiveScan(T v, T *sWave /*[kBlock / PT_WAVE]*/, T &total)
+{
+	const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+	T inc = waveInclusiveScan(v, lane);
+	if (lane == PT_WAVE - 1) sWave[wave] = inc;
 	__syncthreads();
-	for (int o = 1; o < 1024; o <<= 1)
+	T before = 0, all = 0;
+#pragma unroll
+	for (int w = 0; w < kBlock / PT_WAVE; ++w)
 	{
-		uint32_t v = threadIdx.x >= o ? part[threadIdx.x - o] : 0;
-		__syncthreads();
-		part[threadIdx.x] += v;
-		__syncthreads();
+		T c = sWave[w];
+		if (w < wave) before += c;
+		all += c;
 	}
-	uint32_t run = threadIdx.x ? part[threadIdx.x - 1] : 0;
-	for (size_t i = b; i < e; ++i)
+	__syncthreads();
+	total = all;
+	return before + inc - v;
+}
+
+template <typename T> __global__ void __launch_bounds__(kBlock) k_scan_reduce(const T *data, size_t len, T *sums)
+{
+	__shared__ T sWave[kBlock / PT_WAVE];
+	const size_t base = (size_t)blockIdx.x * kScanTile;
+	T s = 0;
+#pragma unroll
+	for (int r = 0; r < kScanItems; ++r)
 	{
-		uint32_t v = data[i];
-		data[i] = run;
-		run += v;
+		size_t i = base + (size_t)r * kBlock + threadIdx.x;  // coalesced; the order inside the tile does not matter here
+		if (i < len) s += data[i];
 	}
+	T total;
+	blockExclusiveScan(s, sWave, total);
+	if (threadIdx.x == 0) sums[blockIdx.x] = total;
+}
+
+// In-place exclusive scan of the tile, plus offsets[blockIdx.x] when given; totalOut (single-tile launches only)
+// receives the sum of everything.
+template <typename T>
+__global__ void __launch_bounds__(kBlock) k_scan_apply(T *data, size_t len, const T *offsets, T *totalOut)
+{
+	__shared__ T sWave[kBlock / PT_WAVE];
+	const size_t base = (size_t)blockIdx.x * kScanTile + (size_t)threadIdx.x * kScanItems;
+	T v[kScanItems];
+	T s = 0;
+#pragma unroll
+	for (int r = 0; r < kScanItems; ++r)
+	{
+		v[r] = base + r < len ? data[base + r] : (T)0;
+		s += v[r];
+	}
+	T total;
+	T run = blockExclusiveScan(s, sWave, total) + (offsets ? offsets[blockIdx.x] : (T)0);
+#pragma unroll
+	for (int r = 0; r < kScanItems; ++r)
+	{
+		if (base + r < len) data[base + r] = run;
+		run += v[r];
+	}
+	if (totalOut && threadIdx.x == 0) *totalOut = total;
+}
+
+// Number of scratch elements scanExclusive needs for `len` items.
+static size_t scanScratchLen(size_t len)
+{
+	size_t total = 0;
+	while (len > (size_t)kScanTile)
+	{
+		len = (len + kScanTile - 1) / kScanTile;
+		total += (len + 63) & ~(size_t)63;
+	}
+	return total + 64;
+}
+
+template <typename T> static void scanExclusive(T *data, size_t len, T *scratch, T *totalOut, hipStream_t stream)
+{
+	if (len <= (size_t)kScanTile)
+	{
+		k_scan_apply<T><<<1, kBlock, 0, stream>>>(data, len, nullptr, totalOut);
+		return;
+	}
+	const size_t nb = (len + kScanTile - 1) / kScanTile;
+	k_scan_reduce<T><<<(uint32_t)nb, kBlock, 0, stream>>>(data, len, scratch);
+	scanExclusive<T>(scratch, nb, scratch + ((nb + 63) & ~(size_t)63), totalOut, stream);
+	k_scan_apply<T><<<(uint32_t)nb, kBlock, 0, stream>>>(data, len, scratch, nullptr);
 }
 
 __global__ void __launch_bounds__(kBlock) k_radix_scatter(const uint32_t *keysIn, const uint32_t *valsIn,
@@ -393,9 +472,9 @@ __device__ __forceinline__ float halfArea(const float *box)
 
 __global__ void __launch_bounds__(kBlock)
     k_collapse_level(const CollapseTask *tasksIn, uint32_t nIn, CollapseTask *tasksOut, uint32_t *nOut, int n,
-                     const int2 *children, const uint32_t *subCount, const float *boxes, const uint32_t *sortedPrim,
-                     const PtVertex *verts, const uint32_t *indices, PtNode4 *nodes, uint32_t *nodeCount,
-                     PtTri48 *tris, uint32_t *triCount, int leafMax, uint32_t nodeBase)
+                     const int2 *children, const int2 *range, const uint32_t *subCount, const float *boxes,
+                     const uint32_t *sortedPrim, bool boxMode, uint32_t *leafPrim, PtNode4 *nodes, uint32_t *nodeCount,
+                     uint32_t *triCount, int leafMax, uint32_t nodeBase)
 {
 	uint32_t ti = blockIdx.x * kBlock + threadIdx.x;
 	if (ti >= nIn) return;
@@ -503,7 +582,17 @@ __global__ void __launch_bounds__(kBlock)
 		int cnt = (int)subCount[slot[s]];
 		if (cnt <= leafMax)
 		{
-			// gather the primitives of the subtree, left to right (LBVH: ascending Morton order)
+			if (!leafPrim)
+			{
+				// Box mode (leafMax == 1): the leaf reference is the primitive (instance) index itself.
+				// LBVH: a subtree covers consecutive sorted positions and the triangle array is in sorted order,
+				// so the leaf is (first position, count) -- nothing to gather, nothing to allocate.
+				const int nd = slot[s];
+				const uint32_t first = nd >= n - 1 ? (uint32_t)(nd - (n - 1)) : (uint32_t)range[nd].x;
+				node.child[s] = boxMode ? (PT_LEAF_FLAG | sortedPrim[first]) : (PT_LEAF_FLAG | ((uint32_t)(cnt - 1) << 28) | first);
+				continue;
+			}
+			// PLOC: gather the primitives of the subtree left to right and give them consecutive slots
 			uint32_t prims[PT_LEAF_MAX];
 			int np = 0, dfs[PT_LEAF_MAX + 1], dsp = 0;
 			dfs[dsp++] = slot[s];
@@ -518,37 +607,8 @@ __global__ void __launch_bounds__(kBlock)
 					dfs[dsp++] = ch.x;
 				}
 			}
-			if (!verts)
-			{
-				// box mode (leafMax == 1): the leaf reference is the primitive (instance) index itself
-				atomicAdd(triCount, 1u);
-				node.child[s] = PT_LEAF_FLAG | prims[0];
-				continue;
-			}
 			uint32_t base = atomicAdd(triCount, (uint32_t)cnt);
-			for (int t = 0; t < cnt; ++t)
-			{
-				uint32_t prim = prims[t];
-				PtTri48 tr;
-				const float *p0 = verts[indices[3 * (size_t)prim + 0]].pos;
-				const float *p1 = verts[indices[3 * (size_t)prim + 1]].pos;
-				const float *p2 = verts[indices[3 * (size_t)prim + 2]].pos;
-				tr.prim = prim;
-				tr.pad[0] = tr.pad[1] = 0;
-				// plane r holds the coordinates in the order ((r+1)%3, (r+2)%3, r): the watertight test of a ray
-				// whose dominant axis is r reads them without per-lane selects.  Plane 2 is the identity.
-				for (int r = 0; r < 3; ++r)
-				{
-					for (int a = 0; a < 3; ++a)
-					{
-						int src = (r + 1 + a) % 3;
-						tr.v0[a] = p0[src];
-						tr.v1[a] = p1[src];
-						tr.v2[a] = p2[src];
-					}
-					tris[(size_t)r * n + base + t] = tr;
-				}
-			}
+			for (int t = 0; t < cnt; ++t) leafPrim[base + t] = prims[t];
 			node.child[s] = PT_LEAF_FLAG | ((uint32_t)(cnt - 1) << 28) | base;
 		}
 		else
@@ -563,6 +623,31 @@ __global__ void __launch_bounds__(kBlock)
 	nodes[task.out] = node;
 }
 
+
+// Leaf-ordered triangle records: slot j holds primitive leafPrim[j]; plane r holds the coordinates in the order
+// ((r+1)%3, (r+2)%3, r) so that the watertight test of a ray whose dominant axis is r reads them without per-lane
+// selects (plane 2 is the identity).  One thread per slot: three 16-byte stores per plane, consecutive lanes write
+// consecutive 48-byte records.
+__global__ void __launch_bounds__(kBlock) k_write_tris(const uint32_t *leafPrim, uint32_t n, const PtVertex *verts,
+                                                       const uint32_t *indices, PtTri48 *tris)
+{
+	uint32_t j = blockIdx.x * kBlock + threadIdx.x;
+	if (j >= n) return;
+	const uint32_t prim = leafPrim[j];
+	const float *p0 = verts[indices[3 * (size_t)prim + 0]].pos;
+	const float *p1 = verts[indices[3 * (size_t)prim + 1]].pos;
+	const float *p2 = verts[indices[3 * (size_t)prim + 2]].pos;
+	const float a[3] = { p0[0], p0[1], p0[2] }, b[3] = { p1[0], p1[1], p1[2] }, c[3] = { p2[0], p2[1], p2[2] };
+#pragma unroll
+	for (int r = 0; r < 3; ++r)
+	{
+		const int x = (r + 1) % 3, y = (r + 2) % 3, z = r;
+		float4 *dst = reinterpret_cast<float4 *>(tris + (size_t)r * n + j);
+		dst[0] = make_float4(a[x], a[y], a[z], b[x]);
+		dst[1] = make_float4(b[y], b[z], c[x], c[y]);
+		dst[2] = make_float4(c[z], __uint_as_float(prim), 0.0f, 0.0f);
+	}
+}
 
 // subtree leaf counts of the LBVH (internal node i covers sorted positions range[i].x .. range[i].y)
 __global__ void __launch_bounds__(kBlock) k_lbvh_counts(const int2 *range, int n, uint32_t *subCount)
@@ -625,76 +710,55 @@ __global__ void __launch_bounds__(kBlock) k_ploc_nearest(const uint32_t *cluster
 	nearest[i] = bestJ;
 }
 
-// keep[i] = cluster i survives at its position (alone, or as the merged pair's lower index);
-// merge[i] = cluster i is the lower index of a mutual pair and creates an internal node.
-__global__ void __launch_bounds__(kBlock) k_ploc_flags(const uint32_t *nearest, uint32_t m, uint32_t *keep,
-                                                       uint32_t *merge)
+// Flags of cluster i (recomputed from `nearest` wherever they are needed): keep = survives at its position (alone,
+// or as the lower index of a merged pair); merge = lower index of a mutual pair, creates an internal node.
+// Packed as keep | merge << 32 so that one 64-bit scan carries both counts.
+__device__ __forceinline__ unsigned long long plocFlags(const uint32_t *nearest, uint32_t i, uint32_t &j, bool &mutual)
 {
-	uint32_t i = blockIdx.x * kBlock + threadIdx.x;
-	if (i >= m) return;
-	uint32_t j = nearest[i];
-	bool mutual = j != i && nearest[j] == i;
-	keep[i] = (mutual && j < i) ? 0u : 1u;
-	merge[i] = (mutual && i < j) ? 1u : 0u;
+	j = nearest[i];
+	mutual = j != i && nearest[j] == i;
+	const unsigned long long keep = (mutual && j < i) ? 0ull : 1ull, merge = (mutual && i < j) ? 1ull : 0ull;
+	return keep | (merge << 32);
 }
 
-__global__ void __launch_bounds__(kBlock)
-    k_ploc_apply(const uint32_t *cluster, const uint32_t *nearest, uint32_t m, const uint32_t *keepScan,
-                 const uint32_t *mergeScan, uint32_t internalBase, float *boxes, uint32_t *subCount, int2 *children,
-                 uint32_t *clusterOut)
+// One (keep, merge) sum per block of kBlock clusters.
+__global__ void __launch_bounds__(kBlock) k_ploc_count(const uint32_t *nearest, uint32_t m, unsigned long long *sums)
 {
-	uint32_t i = blockIdx.x * kBlock + threadIdx.x;
-	if (i >= m) return;
-	uint32_t j = nearest[i];
-	bool mutual = j != i && nearest[j] == i;
-	if (mutual && j < i) return;  // absorbed by its partner
+	__shared__ unsigned long long sWave[kBlock / PT_WAVE];
+	uint32_t i = blockIdx.x * kBlock + threadIdx.x, j;
+	bool mutual;
+	unsigned long long f = i < m ? plocFlags(nearest, i, j, mutual) : 0ull, total;
+	blockExclusiveScan(f, sWave, total);
+	if (threadIdx.x == 0) sums[blockIdx.x] = total;
+}
+
+// sums: exclusive scan of k_ploc_count's output.  Compacts the survivors in order and creates the internal nodes
+// (numbered internalBase + exclusive scan of the merge flags: deterministic).
+__global__ void __launch_bounds__(kBlock)
+    k_ploc_apply(const uint32_t *cluster, const uint32_t *nearest, uint32_t m, const unsigned long long *sums,
+                 uint32_t internalBase, float *boxes, uint32_t *subCount, int2 *children, uint32_t *clusterOut)
+{
+	__shared__ unsigned long long sWave[kBlock / PT_WAVE];
+	uint32_t i = blockIdx.x * kBlock + threadIdx.x, j = 0;
+	bool mutual = false;
+	unsigned long long f = i < m ? plocFlags(nearest, i, j, mutual) : 0ull, total;
+	unsigned long long ex = blockExclusiveScan(f, sWave, total) + sums[blockIdx.x];
+	if (i >= m || (mutual && j < i)) return;  // absorbed by its partner
 	uint32_t id = cluster[i];
 	if (mutual)
 	{
 		uint32_t a = id, b = cluster[j];
-		id = internalBase + mergeScan[i];
-		const float *ba = boxes + 8 * (size_t)a, *bb = boxes + 8 * (size_t)b;
-		float *bo = boxes + 8 * (size_t)id;
-		for (int k = 0; k < 3; ++k)
-		{
-			bo[k] = fminf(ba[k], bb[k]);
-			bo[4 + k] = fmaxf(ba[4 + k], bb[4 + k]);
-		}
-		bo[3] = bo[7] = 0.0f;
+		id = internalBase + (uint32_t)(ex >> 32);
+		const float4 *ba = reinterpret_cast<const float4 *>(boxes + 8 * (size_t)a);
+		const float4 *bb = reinterpret_cast<const float4 *>(boxes + 8 * (size_t)b);
+		float4 *bo = reinterpret_cast<float4 *>(boxes + 8 * (size_t)id);
+		float4 alo = ba[0], ahi = ba[1], blo = bb[0], bhi = bb[1];
+		bo[0] = make_float4(fminf(alo.x, blo.x), fminf(alo.y, blo.y), fminf(alo.z, blo.z), 0.0f);
+		bo[1] = make_float4(fmaxf(ahi.x, bhi.x), fmaxf(ahi.y, bhi.y), fmaxf(ahi.z, bhi.z), 0.0f);
 		subCount[id] = subCount[a] + subCount[b];
 		children[id] = make_int2((int)a, (int)b);
 	}
-	clusterOut[keepScan[i]] = id;
-}
-
-// totals[0] = clusters left, totals[1] = merges of this iteration; run between the flags and the scans
-__global__ void __launch_bounds__(1024) k_ploc_totals(const uint32_t *keep, const uint32_t *merge, uint32_t m,
-                                                      uint32_t *totals)
-{
-	__shared__ uint32_t sk[1024], sm[1024];
-	uint32_t k = 0, g = 0;
-	for (uint32_t i = threadIdx.x; i < m; i += 1024)
-	{
-		k += keep[i];
-		g += merge[i];
-	}
-	sk[threadIdx.x] = k;
-	sm[threadIdx.x] = g;
-	__syncthreads();
-	for (int o = 512; o > 0; o >>= 1)
-	{
-		if ((int)threadIdx.x < o)
-		{
-			sk[threadIdx.x] += sk[threadIdx.x + o];
-			sm[threadIdx.x] += sm[threadIdx.x + o];
-		}
-		__syncthreads();
-	}
-	if (threadIdx.x == 0)
-	{
-		totals[0] = sk[0];
-		totals[1] = sm[0];
-	}
+	clusterOut[(uint32_t)ex] = id;
 }
 
 __global__ void k_init_bounds(int *bounds)
@@ -723,51 +787,52 @@ hipError_t ptBuildBvh4(const PtBuildInput &in, PtBuildOutput &out, hipStream_t s
 	out = PtBuildOutput();
 	if (n == 0) return hipSuccess;
 	if (n > 0x0FFFFFFFu) return hipErrorInvalidValue;
-
-	// ---- scratch (freed on exit) ----
-	float4 *triLo = nullptr, *triHi = nullptr;
-	int *bounds = nullptr;
-	uint32_t *keysA = nullptr, *keysB = nullptr, *valsA = nullptr, *valsB = nullptr, *hist = nullptr;
-	int2 *children = nullptr, *range = nullptr;
-	int *parent = nullptr;
-	float *boxes = nullptr;
-	unsigned int *arrive = nullptr;
-	uint32_t *subCount = nullptr, *clusterA = nullptr, *clusterB = nullptr, *nearest = nullptr, *keep = nullptr,
-	         *merge = nullptr;
 	const bool ploc = in.builder == PT_BUILDER_PLOC;
-	CollapseTask *taskA = nullptr, *taskB = nullptr;
-	uint32_t *counters = nullptr;  // [0]=nodeCount [1]=triCount [2]=queue count
+
+	// ---- scratch: ONE allocation carved into 256-byte aligned pieces (hipMalloc/hipFree of two dozen multi-GB
+	// buffers cost more than the build itself), freed on exit ----
 	const uint32_t nSortBlocks = divUp(n, kTile);
 	const size_t histLen = (size_t)256 * nSortBlocks;
 	const size_t nNodes2 = 2 * (size_t)n - 1;
-	hipError_t err = hipSuccess;
+	const uint32_t plocBlocks = divUp(n, kBlock);
+	size_t arenaBytes = 0;
+	auto reserve = [&](size_t bytes) {
+		size_t at = arenaBytes;
+		arenaBytes += (bytes + 255) & ~(size_t)255;
+		return at;
+	};
+	const size_t oTriLo = reserve(sizeof(float4) * n), oTriHi = reserve(sizeof(float4) * n), oBounds = reserve(64);
+	const size_t oKeysA = reserve(4 * (size_t)n), oKeysB = reserve(4 * (size_t)n), oValsA = reserve(4 * (size_t)n),
+	             oValsB = reserve(4 * (size_t)n);
+	const size_t oHist = reserve(4 * histLen), oScan = reserve(4 * scanScratchLen(histLen));
+	const size_t oChildren = reserve(sizeof(int2) * n), oRange = reserve(sizeof(int2) * n);
+	const size_t oParent = reserve(sizeof(int) * nNodes2), oBoxes = reserve(sizeof(float) * 8 * nNodes2);
+	const size_t oArrive = reserve(sizeof(unsigned int) * n), oSubCount = reserve(sizeof(uint32_t) * nNodes2);
+	const size_t oClusterA = reserve(ploc ? 4 * (size_t)n : 0), oClusterB = reserve(ploc ? 4 * (size_t)n : 0),
+	             oNearest = reserve(ploc ? 4 * (size_t)n : 0), oLeafPrim = reserve(ploc && !boxMode ? 4 * (size_t)n : 0);
+	const size_t oPlocSums = reserve(ploc ? 8 * (((size_t)plocBlocks + 63) / 64 * 64 + scanScratchLen(plocBlocks)) : 0);
+	const size_t oPlocTotal = reserve(64);
+	const size_t oTaskA = reserve(sizeof(CollapseTask) * n), oTaskB = reserve(sizeof(CollapseTask) * n), oCounters = reserve(64);
+	char *arena = nullptr;
+	hipError_t err = hipMalloc(&arena, arenaBytes);
 #define TRY(x)                      \
 	if (err == hipSuccess) err = (x)
-	TRY(hipMalloc(&triLo, sizeof(float4) * n));
-	TRY(hipMalloc(&triHi, sizeof(float4) * n));
-	TRY(hipMalloc(&bounds, sizeof(int) * 8));
-	TRY(hipMalloc(&keysA, 4 * (size_t)n));
-	TRY(hipMalloc(&keysB, 4 * (size_t)n));
-	TRY(hipMalloc(&valsA, 4 * (size_t)n));
-	TRY(hipMalloc(&valsB, 4 * (size_t)n));
-	TRY(hipMalloc(&hist, 4 * histLen));
-	TRY(hipMalloc(&children, sizeof(int2) * n));
-	TRY(hipMalloc(&range, sizeof(int2) * n));
-	TRY(hipMalloc(&parent, sizeof(int) * nNodes2));
-	TRY(hipMalloc(&boxes, sizeof(float) * 8 * nNodes2));
-	TRY(hipMalloc(&arrive, sizeof(unsigned int) * n));
-	TRY(hipMalloc(&subCount, sizeof(uint32_t) * nNodes2));
-	if (ploc)
-	{
-		TRY(hipMalloc(&clusterA, 4 * (size_t)n));
-		TRY(hipMalloc(&clusterB, 4 * (size_t)n));
-		TRY(hipMalloc(&nearest, 4 * (size_t)n));
-		TRY(hipMalloc(&keep, 4 * (size_t)n));
-		TRY(hipMalloc(&merge, 4 * (size_t)n));
-	}
-	TRY(hipMalloc(&taskA, sizeof(CollapseTask) * n));
-	TRY(hipMalloc(&taskB, sizeof(CollapseTask) * n));
-	TRY(hipMalloc(&counters, sizeof(uint32_t) * 4));
+#define AT(T, off) reinterpret_cast<T *>(arena + (off))
+	float4 *triLo = AT(float4, oTriLo), *triHi = AT(float4, oTriHi);
+	int *bounds = AT(int, oBounds);
+	uint32_t *keysA = AT(uint32_t, oKeysA), *keysB = AT(uint32_t, oKeysB), *valsA = AT(uint32_t, oValsA),
+	         *valsB = AT(uint32_t, oValsB), *hist = AT(uint32_t, oHist), *scanScratch = AT(uint32_t, oScan);
+	int2 *children = AT(int2, oChildren), *range = AT(int2, oRange);
+	int *parent = AT(int, oParent);
+	float *boxes = AT(float, oBoxes);
+	unsigned int *arrive = AT(unsigned int, oArrive);
+	uint32_t *subCount = AT(uint32_t, oSubCount), *clusterA = AT(uint32_t, oClusterA), *clusterB = AT(uint32_t, oClusterB),
+	         *nearest = AT(uint32_t, oNearest), *leafPrim = ploc && !boxMode ? AT(uint32_t, oLeafPrim) : nullptr;
+	unsigned long long *plocSums = AT(unsigned long long, oPlocSums);
+	uint32_t *plocTotal = AT(uint32_t, oPlocTotal);  // one packed (keep, merge) pair = two uint32
+	CollapseTask *taskA = AT(CollapseTask, oTaskA), *taskB = AT(CollapseTask, oTaskB);
+	uint32_t *counters = AT(uint32_t, oCounters);  // [0]=nodeCount [1]=triCount [2]=queue count
+#undef AT
 	// outputs
 	PtNode4 *nodes = nullptr;
 	PtTri48 *tris = nullptr;
@@ -791,7 +856,7 @@ hipError_t ptBuildBvh4(const PtBuildInput &in, PtBuildOutput &out, hipStream_t s
 		for (int shift = 0; shift < 32; shift += 8)
 		{
 			k_radix_hist<<<nSortBlocks, kBlock, 0, stream>>>(kin, n, shift, hist, nSortBlocks);
-			k_exclusive_scan<<<1, 1024, 0, stream>>>(hist, histLen);
+			scanExclusive<uint32_t>(hist, histLen, scanScratch, nullptr, stream);
 			k_radix_scatter<<<nSortBlocks, kBlock, 0, stream>>>(kin, vin, kout, vout, n, shift, hist, nSortBlocks);
 			uint32_t *t = kin;
 			kin = kout;
@@ -811,6 +876,8 @@ hipError_t ptBuildBvh4(const PtBuildInput &in, PtBuildOutput &out, hipStream_t s
 			k_refit<<<gridTris, kBlock, 0, stream>>>(triLo, triHi, vin, (int)n, children, parent, bounds, boxes, arrive,
 			                                         padScale);
 			k_lbvh_counts<<<gridTris, kBlock, 0, stream>>>(range, (int)n, subCount);
+			// the triangle array is in sorted order: independent of the collapse
+			if (!boxMode) k_write_tris<<<gridTris, kBlock, 0, stream>>>(vin, n, in.vertices, in.indices, tris);
 		}
 		if (err == hipSuccess && ploc)
 		{
@@ -822,14 +889,12 @@ hipError_t ptBuildBvh4(const PtBuildInput &in, PtBuildOutput &out, hipStream_t s
 			{
 				const uint32_t g = divUp(m, kBlock);
 				k_ploc_nearest<<<g, kBlock, 0, stream>>>(cin, m, boxes, nearest);
-				k_ploc_flags<<<g, kBlock, 0, stream>>>(nearest, m, keep, merge);
-				k_ploc_totals<<<1, 1024, 0, stream>>>(keep, merge, m, counters);
-				k_exclusive_scan<<<1, 1024, 0, stream>>>(keep, m);
-				k_exclusive_scan<<<1, 1024, 0, stream>>>(merge, m);
-				k_ploc_apply<<<g, kBlock, 0, stream>>>(cin, nearest, m, keep, merge, created, boxes, subCount, children,
-				                                       cout);
+				k_ploc_count<<<g, kBlock, 0, stream>>>(nearest, m, plocSums);
+				scanExclusive<unsigned long long>(plocSums, g, plocSums + (((size_t)g + 63) & ~(size_t)63),
+				                                  reinterpret_cast<unsigned long long *>(plocTotal), stream);
+				k_ploc_apply<<<g, kBlock, 0, stream>>>(cin, nearest, m, plocSums, created, boxes, subCount, children, cout);
 				uint32_t h[2];
-				err = hipMemcpyAsync(h, counters, sizeof(h), hipMemcpyDeviceToHost, stream);
+				err = hipMemcpyAsync(h, plocTotal, sizeof(h), hipMemcpyDeviceToHost, stream);  // (clusters left, merges)
 				TRY(hipStreamSynchronize(stream));
 				if (err != hipSuccess) break;
 				// the globally closest pair inside the window is always mutual, so every pass merges at least once
@@ -854,9 +919,9 @@ hipError_t ptBuildBvh4(const PtBuildInput &in, PtBuildOutput &out, hipStream_t s
 		{
 			++depth;
 			k_collapse_level<<<divUp(nIn, kBlock), kBlock, 0, stream>>>(tin, nIn, tout, counters + 2, (int)n, children,
-			                                                          subCount, boxes, vin, boxMode ? nullptr : in.vertices,
-			                                                          in.indices, nodes, counters, tris, counters + 1,
-			                                                          leafMax, in.nodeBase);
+			                                                          ploc ? nullptr : range, subCount, boxes, vin, boxMode,
+			                                                          leafPrim, nodes, counters, counters + 1, leafMax,
+			                                                          in.nodeBase);
 			uint32_t h[4];
 			err = hipMemcpyAsync(h, counters, sizeof(h), hipMemcpyDeviceToHost, stream);
 			TRY(hipStreamSynchronize(stream));
@@ -869,6 +934,7 @@ hipError_t ptBuildBvh4(const PtBuildInput &in, PtBuildOutput &out, hipStream_t s
 			tin = tout;
 			tout = t;
 		}
+		if (err == hipSuccess && leafPrim) k_write_tris<<<gridTris, kBlock, 0, stream>>>(leafPrim, n, in.vertices, in.indices, tris);
 		TRY(hipGetLastError());
 	}
 	if (err == hipSuccess)
@@ -882,10 +948,8 @@ hipError_t ptBuildBvh4(const PtBuildInput &in, PtBuildOutput &out, hipStream_t s
 		}
 	}
 #undef TRY
-	hipFree(triLo); hipFree(triHi); hipFree(bounds); hipFree(keysA); hipFree(keysB); hipFree(valsA); hipFree(valsB);
-	hipFree(hist); hipFree(children); hipFree(range); hipFree(parent); hipFree(boxes); hipFree(arrive);
-	hipFree(subCount); hipFree(clusterA); hipFree(clusterB); hipFree(nearest); hipFree(keep); hipFree(merge);
-	hipFree(taskA); hipFree(taskB); hipFree(counters);
+	hipStreamSynchronize(stream);
+	hipFree(arena);
 	if (err != hipSuccess)
 	{
 		hipFree(nodes); hipFree(tris); hipFree(codes); hipFree(order);
