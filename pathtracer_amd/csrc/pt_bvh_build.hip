@@ -424,35 +424,82 @@ __device__ __forceinline__ void loadBox(const float *src, float lo[3], float hi[
 	}
 }
 
+// One thread per leaf walks towards the root; at every internal node the first arrival stops and the second one
+// (which then knows both children are finished) forms the union.  A thread carries its own box in registers and
+// reads only the sibling's.  Two protocols:
+//   * LOCAL: while the parent's range of sorted positions lies inside this block's 256 leaves, its index does too
+//     (a Karras node sits at one end of its range), so arrival counters and sibling boxes live in LDS -- 99 % of the
+//     nodes, no global atomics, no cross-CU traffic;
+//   * GLOBAL (the top of the tree): the box is published with agent-scope stores, the lane drains its stores
+//     (s_waitcnt vmcnt(0)), then an agent-scope atomic counts the arrival and the sibling's box is read with
+//     agent-scope loads (MI355X_MICROARCH.md, cross-CU hand-off inside a launch).
+// Every node's box is also written to `boxes` for the collapse kernel.
 __global__ void __launch_bounds__(kBlock) k_refit(const float4 *triLo, const float4 *triHi, const uint32_t *sortedPrim,
-                                                  int n, const int2 *children, const int *parent, const int *bounds,
-                                                  float *boxes, unsigned int *arrive, float padScale)
+                                                  int n, const int2 *children, const int *parent, const int2 *range,
+                                                  const int *bounds, float *boxes, unsigned int *arrive, float padScale)
 {
-	int k = blockIdx.x * kBlock + threadIdx.x;
+	__shared__ float sBox[6][2 * kBlock];  // slot: internal node i -> i - base, leaf k -> kBlock + k - base
+	__shared__ unsigned int sArrive[kBlock];
+	const int base = blockIdx.x * kBlock, k = base + threadIdx.x;
+	sArrive[threadIdx.x] = 0;
+	__syncthreads();
 	if (k >= n) return;
 	const float pad = __uint_as_float((unsigned int)bounds[6]) * padScale;  // 2^-18 * max|coord| for triangles
 	uint32_t prim = sortedPrim[k];
 	float4 l4 = triLo[prim], h4 = triHi[prim];
 	float lo[3] = { l4.x - pad, l4.y - pad, l4.z - pad }, hi[3] = { h4.x + pad, h4.y + pad, h4.z + pad };
-	int node = (n - 1) + k;
-	storeBox(boxes + 8 * (size_t)node, lo, hi);
-	int p = parent[node];
-	while (p >= 0)
+	int cur = (n - 1) + k;
+	int p = parent[cur];
+	bool local = true;
+	for (;;)
 	{
-		asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-		unsigned int old = __hip_atomic_fetch_add(&arrive[p], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-		if (old == 0) return;  // the sibling subtree finishes this node
-		int2 ch = children[p];
-		float lo2[3], hi2[3];
-		loadBox(boxes + 8 * (size_t)ch.x, lo, hi);
-		loadBox(boxes + 8 * (size_t)ch.y, lo2, hi2);
-#pragma unroll
-		for (int a = 0; a < 3; ++a)
+		float4 *dst = reinterpret_cast<float4 *>(boxes + 8 * (size_t)cur);
+		dst[0] = make_float4(lo[0], lo[1], lo[2], 0.0f);
+		dst[1] = make_float4(hi[0], hi[1], hi[2], 0.0f);
+		if (p < 0) return;  // cur is the root
+		if (local)
 		{
-			lo[a] = fminf(lo[a], lo2[a]);
-			hi[a] = fmaxf(hi[a], hi2[a]);
+			const int2 r = range[p];
+			local = r.x >= base && r.y < base + kBlock;
 		}
-		storeBox(boxes + 8 * (size_t)p, lo, hi);
+		const int2 ch = children[p];
+		const int sib = ch.x == cur ? ch.y : ch.x;
+		if (local)
+		{
+			const int slot = cur >= n - 1 ? kBlock + (cur - (n - 1) - base) : cur - base;
+#pragma unroll
+			for (int a = 0; a < 3; ++a)
+			{
+				sBox[a][slot] = lo[a];
+				sBox[3 + a][slot] = hi[a];
+			}
+			__threadfence_block();
+			if (atomicAdd(&sArrive[p - base], 1u) == 0u) return;  // the sibling subtree finishes this node
+			__threadfence_block();
+			const int ss = sib >= n - 1 ? kBlock + (sib - (n - 1) - base) : sib - base;
+#pragma unroll
+			for (int a = 0; a < 3; ++a)
+			{
+				lo[a] = fminf(lo[a], sBox[a][ss]);
+				hi[a] = fmaxf(hi[a], sBox[3 + a][ss]);
+			}
+		}
+		else
+		{
+			storeBox(boxes + 8 * (size_t)cur, lo, hi);
+			asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+			unsigned int old = __hip_atomic_fetch_add(&arrive[p], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+			if (old == 0) return;
+			float lo2[3], hi2[3];
+			loadBox(boxes + 8 * (size_t)sib, lo2, hi2);
+#pragma unroll
+			for (int a = 0; a < 3; ++a)
+			{
+				lo[a] = fminf(lo[a], lo2[a]);
+				hi[a] = fmaxf(hi[a], hi2[a]);
+			}
+		}
+		cur = p;
 		p = parent[p];
 	}
 }
@@ -470,62 +517,95 @@ __device__ __forceinline__ float halfArea(const float *box)
 	return (dx * dy + dy * dz) + dz * dx;
 }
 
+// One thread per wide node of the level.  Children that stay inner nodes become the tasks of the next level; their
+// node ids are childBase + position in that queue (breadth-first numbering), so ONE block-aggregated atomic hands
+// out both (a per-child atomic on a single counter serialises: 4 ms of a 20 M-triangle build).
 __global__ void __launch_bounds__(kBlock)
     k_collapse_level(const CollapseTask *tasksIn, uint32_t nIn, CollapseTask *tasksOut, uint32_t *nOut, int n,
                      const int2 *children, const int2 *range, const uint32_t *subCount, const float *boxes,
-                     const uint32_t *sortedPrim, bool boxMode, uint32_t *leafPrim, PtNode4 *nodes, uint32_t *nodeCount,
+                     const uint32_t *sortedPrim, bool boxMode, uint32_t *leafPrim, PtNode4 *nodes, uint32_t childBase,
                      uint32_t *triCount, int leafMax, uint32_t nodeBase)
 {
-	uint32_t ti = blockIdx.x * kBlock + threadIdx.x;
-	if (ti >= nIn) return;
-	CollapseTask task = tasksIn[ti];
-
-	int slot[4];
+	__shared__ unsigned long long sWave[kBlock / PT_WAVE];
+	__shared__ uint32_t sBase[2];
+	const uint32_t ti = blockIdx.x * kBlock + threadIdx.x;
+	const bool active = ti < nIn;
+	CollapseTask task = { 0, 0u };
+	int slot[4] = { 0, 0, 0, 0 };
+	uint32_t cnt[4] = { 0, 0, 0, 0 };
 	int nSlots = 0;
+	if (active)
 	{
-		if ((int)subCount[task.bvh2] <= leafMax)
-			slot[nSlots++] = task.bvh2;  // whole subtree is one leaf child
+		task = tasksIn[ti];
+		const uint32_t rootCount = subCount[task.bvh2];
+		if ((int)rootCount <= leafMax)
+		{
+			slot[0] = task.bvh2;  // whole subtree is one leaf child
+			cnt[0] = rootCount;
+			nSlots = 1;
+		}
 		else
 		{
+			float area[4] = { 0, 0, 0, 0 };
+			auto put = [&](int s, int nd) {
+				slot[s] = nd;
+				cnt[s] = subCount[nd];
+				area[s] = (int)cnt[s] <= leafMax ? -1.0f : halfArea(boxes + 8 * (size_t)nd);  // leaf children are never opened
+			};
 			int2 ch = children[task.bvh2];
-			slot[0] = ch.x;
-			slot[1] = ch.y;
+			put(0, ch.x);
+			put(1, ch.y);
 			nSlots = 2;
 			while (nSlots < 4)
 			{
 				int best = -1;
 				float bestArea = -1.0f;
 				for (int s = 0; s < nSlots; ++s)
-				{
-					if ((int)subCount[slot[s]] <= leafMax) continue;  // stays a leaf child
-					float a = halfArea(boxes + 8 * (size_t)slot[s]);
-					if (a > bestArea)
+					if (area[s] > bestArea)
 					{
-						bestArea = a;
+						bestArea = area[s];
 						best = s;
 					}
-				}
 				if (best < 0) break;
 				int2 ch2 = children[slot[best]];
-				slot[best] = ch2.x;
-				slot[nSlots++] = ch2.y;
+				put(best, ch2.x);
+				put(nSlots++, ch2.y);
 			}
 		}
 	}
+	// queue positions / node ids of the inner children and (PLOC) triangle slots of the leaf children
+	uint32_t nInner = 0, nLeafTris = 0;
+	for (int s = 0; s < nSlots; ++s)
+	{
+		if ((int)cnt[s] <= leafMax) nLeafTris += cnt[s];
+		else ++nInner;
+	}
+	unsigned long long total;
+	const unsigned long long ex = blockExclusiveScan((unsigned long long)nInner | ((unsigned long long)nLeafTris << 32), sWave, total);
+	if (threadIdx.x == 0)
+	{
+		sBase[0] = (uint32_t)total ? atomicAdd(nOut, (uint32_t)total) : 0u;
+		sBase[1] = (leafPrim && (uint32_t)(total >> 32)) ? atomicAdd(triCount, (uint32_t)(total >> 32)) : 0u;
+	}
+	__syncthreads();
+	if (!active) return;
+	uint32_t q = sBase[0] + (uint32_t)ex, triBase = sBase[1] + (uint32_t)(ex >> 32);
 
 	// node frame: origin = min corner, power-of-two scale per axis covering the extent in 255 steps
+	float4 blo[4], bhi[4];
 	float org[3] = { INFINITY, INFINITY, INFINITY }, top[3] = { -INFINITY, -INFINITY, -INFINITY };
 	for (int s = 0; s < nSlots; ++s)
 	{
-		const float *b = boxes + 8 * (size_t)slot[s];
-#pragma unroll
-		for (int a = 0; a < 3; ++a)
-		{
-			org[a] = fminf(org[a], b[a]);
-			top[a] = fmaxf(top[a], b[4 + a]);
-		}
+		const float4 *b = reinterpret_cast<const float4 *>(boxes + 8 * (size_t)slot[s]);
+		blo[s] = b[0];
+		bhi[s] = b[1];
+		org[0] = fminf(org[0], blo[s].x);
+		org[1] = fminf(org[1], blo[s].y);
+		org[2] = fminf(org[2], blo[s].z);
+		top[0] = fmaxf(top[0], bhi[s].x);
+		top[1] = fmaxf(top[1], bhi[s].y);
+		top[2] = fmaxf(top[2], bhi[s].z);
 	}
-	uint32_t expBits[3];
 	float scale[3];
 #pragma unroll
 	for (int a = 0; a < 3; ++a)
@@ -534,9 +614,9 @@ __global__ void __launch_bounds__(kBlock)
 		int e = 1;
 		if (ext > 0.0f)
 		{
-			int ex;
-			float m = frexpf(ext / 255.0f, &ex);  // ext/255 = m * 2^ex, m in [0.5,1)
-			e = (m == 0.5f ? ex - 1 : ex) + 127;
+			int ex2;
+			float m = frexpf(ext / 255.0f, &ex2);  // ext/255 = m * 2^ex2, m in [0.5,1)
+			e = (m == 0.5f ? ex2 - 1 : ex2) + 127;
 		}
 		if (e < 1) e = 1;
 		if (e > 254) e = 254;
@@ -546,7 +626,6 @@ __global__ void __launch_bounds__(kBlock)
 			++e;
 			sc = __uint_as_float((uint32_t)e << 23);
 		}
-		expBits[a] = (uint32_t)e;
 		scale[a] = sc;
 	}
 
@@ -566,21 +645,21 @@ __global__ void __launch_bounds__(kBlock)
 
 	for (int s = 0; s < nSlots; ++s)
 	{
-		const float *b = boxes + 8 * (size_t)slot[s];
+		const float lo3[3] = { blo[s].x, blo[s].y, blo[s].z }, hi3[3] = { bhi[s].x, bhi[s].y, bhi[s].z };
 #pragma unroll
 		for (int a = 0; a < 3; ++a)
 		{
-			float ql = floorf((b[a] - org[a]) / scale[a]);
+			float ql = floorf((lo3[a] - org[a]) / scale[a]);
 			ql = fminf(fmaxf(ql, 0.0f), 255.0f);
-			while (ql > 0.0f && __builtin_fmaf(ql, scale[a], org[a]) > b[a]) ql -= 1.0f;
-			float qh = ceilf((b[4 + a] - org[a]) / scale[a]);
+			while (ql > 0.0f && __builtin_fmaf(ql, scale[a], org[a]) > lo3[a]) ql -= 1.0f;
+			float qh = ceilf((hi3[a] - org[a]) / scale[a]);
 			qh = fminf(fmaxf(qh, 0.0f), 255.0f);
-			while (qh < 255.0f && __builtin_fmaf(qh, scale[a], org[a]) < b[4 + a]) qh += 1.0f;
+			while (qh < 255.0f && __builtin_fmaf(qh, scale[a], org[a]) < hi3[a]) qh += 1.0f;
 			node.qlo[a] = (node.qlo[a] & ~(0xFFu << (8 * s))) | ((uint32_t)ql << (8 * s));
 			node.qhi[a] = (node.qhi[a] & ~(0xFFu << (8 * s))) | ((uint32_t)qh << (8 * s));
 		}
-		int cnt = (int)subCount[slot[s]];
-		if (cnt <= leafMax)
+		const int c = (int)cnt[s];
+		if (c <= leafMax)
 		{
 			if (!leafPrim)
 			{
@@ -589,17 +668,16 @@ __global__ void __launch_bounds__(kBlock)
 				// so the leaf is (first position, count) -- nothing to gather, nothing to allocate.
 				const int nd = slot[s];
 				const uint32_t first = nd >= n - 1 ? (uint32_t)(nd - (n - 1)) : (uint32_t)range[nd].x;
-				node.child[s] = boxMode ? (PT_LEAF_FLAG | sortedPrim[first]) : (PT_LEAF_FLAG | ((uint32_t)(cnt - 1) << 28) | first);
+				node.child[s] = boxMode ? (PT_LEAF_FLAG | sortedPrim[first]) : (PT_LEAF_FLAG | ((uint32_t)(c - 1) << 28) | first);
 				continue;
 			}
-			// PLOC: gather the primitives of the subtree left to right and give them consecutive slots
-			uint32_t prims[PT_LEAF_MAX];
+			// PLOC: the primitives of the subtree, left to right, into consecutive slots
 			int np = 0, dfs[PT_LEAF_MAX + 1], dsp = 0;
 			dfs[dsp++] = slot[s];
-			while (dsp > 0 && np < PT_LEAF_MAX)
+			while (dsp > 0 && np < c)
 			{
 				int nd = dfs[--dsp];
-				if (nd >= n - 1) prims[np++] = sortedPrim[nd - (n - 1)];
+				if (nd >= n - 1) leafPrim[triBase + np++] = sortedPrim[nd - (n - 1)];
 				else
 				{
 					int2 ch = children[nd];
@@ -607,17 +685,15 @@ __global__ void __launch_bounds__(kBlock)
 					dfs[dsp++] = ch.x;
 				}
 			}
-			uint32_t base = atomicAdd(triCount, (uint32_t)cnt);
-			for (int t = 0; t < cnt; ++t) leafPrim[base + t] = prims[t];
-			node.child[s] = PT_LEAF_FLAG | ((uint32_t)(cnt - 1) << 28) | base;
+			node.child[s] = PT_LEAF_FLAG | ((uint32_t)(c - 1) << 28) | triBase;
+			triBase += (uint32_t)c;
 		}
 		else
 		{
-			uint32_t idx = atomicAdd(nodeCount, 1u);
-			node.child[s] = idx + nodeBase;
-			uint32_t q = atomicAdd(nOut, 1u);
+			node.child[s] = childBase + q + nodeBase;
 			tasksOut[q].bvh2 = slot[s];
-			tasksOut[q].out = idx;
+			tasksOut[q].out = childBase + q;
+			++q;
 		}
 	}
 	nodes[task.out] = node;
@@ -685,21 +761,38 @@ __global__ void __launch_bounds__(kBlock) k_ploc_leaves(const float4 *triLo, con
 __global__ void __launch_bounds__(kBlock) k_ploc_nearest(const uint32_t *cluster, uint32_t m, const float *boxes,
                                                          uint32_t *nearest)
 {
-	uint32_t i = blockIdx.x * kBlock + threadIdx.x;
+	// the block's window of cluster boxes (256 + 16 either side) is gathered once into LDS; every thread then scans
+	// its 32 neighbours there instead of issuing 32 dependent global gathers
+	constexpr int kWin = kBlock + 2 * kPlocRadius;
+	__shared__ float sB[6][kWin];
+	const long long base = (long long)blockIdx.x * kBlock - kPlocRadius;
+	for (int t = threadIdx.x; t < kWin; t += kBlock)
+	{
+		const long long g = base + t;
+		if (g >= 0 && g < (long long)m)
+		{
+			const float4 *b = reinterpret_cast<const float4 *>(boxes + 8 * (size_t)cluster[g]);
+			const float4 l = b[0], h = b[1];
+			sB[0][t] = l.x; sB[1][t] = l.y; sB[2][t] = l.z;
+			sB[3][t] = h.x; sB[4][t] = h.y; sB[5][t] = h.z;
+		}
+	}
+	__syncthreads();
+	const uint32_t i = blockIdx.x * kBlock + threadIdx.x;
 	if (i >= m) return;
-	const float *bi = boxes + 8 * (size_t)cluster[i];
-	float lo[3] = { bi[0], bi[1], bi[2] }, hi[3] = { bi[4], bi[5], bi[6] };
-	uint32_t j0 = i > (uint32_t)kPlocRadius ? i - kPlocRadius : 0u;
-	uint32_t j1 = i + kPlocRadius < m - 1 ? i + kPlocRadius : m - 1;
+	const int me = threadIdx.x + kPlocRadius;
+	const float lo[3] = { sB[0][me], sB[1][me], sB[2][me] }, hi[3] = { sB[3][me], sB[4][me], sB[5][me] };
+	const uint32_t j0 = i > (uint32_t)kPlocRadius ? i - kPlocRadius : 0u;
+	const uint32_t j1 = i + kPlocRadius < m - 1 ? i + kPlocRadius : m - 1;
 	float best = INFINITY;
 	uint32_t bestJ = i;
 	for (uint32_t j = j0; j <= j1; ++j)
 	{
 		if (j == i) continue;
-		const float *bj = boxes + 8 * (size_t)cluster[j];
-		float dx = fmaxf(hi[0], bj[4]) - fminf(lo[0], bj[0]);
-		float dy = fmaxf(hi[1], bj[5]) - fminf(lo[1], bj[1]);
-		float dz = fmaxf(hi[2], bj[6]) - fminf(lo[2], bj[2]);
+		const int t = (int)((long long)j - base);
+		float dx = fmaxf(hi[0], sB[3][t]) - fminf(lo[0], sB[0][t]);
+		float dy = fmaxf(hi[1], sB[4][t]) - fminf(lo[1], sB[1][t]);
+		float dz = fmaxf(hi[2], sB[5][t]) - fminf(lo[2], sB[2][t]);
 		float a = (dx * dy + dy * dz) + dz * dx;  // symmetric in (i, j): both sides compute the same value
 		if (a < best)
 		{
@@ -873,8 +966,8 @@ hipError_t ptBuildBvh4(const PtBuildInput &in, PtBuildOutput &out, hipStream_t s
 			err = hipMemsetAsync(arrive, 0, sizeof(unsigned int) * n, stream);
 			if (n > 1) k_lbvh_topology<<<divUp(n - 1, kBlock), kBlock, 0, stream>>>(kin, (int)n, children, parent, range);
 			else TRY(hipMemsetAsync(parent, 0xFF, sizeof(int), stream));  // single leaf: parent = -1
-			k_refit<<<gridTris, kBlock, 0, stream>>>(triLo, triHi, vin, (int)n, children, parent, bounds, boxes, arrive,
-			                                         padScale);
+			k_refit<<<gridTris, kBlock, 0, stream>>>(triLo, triHi, vin, (int)n, children, parent, range, bounds, boxes,
+			                                         arrive, padScale);
 			k_lbvh_counts<<<gridTris, kBlock, 0, stream>>>(range, (int)n, subCount);
 			// the triangle array is in sorted order: independent of the collapse
 			if (!boxMode) k_write_tris<<<gridTris, kBlock, 0, stream>>>(vin, n, in.vertices, in.indices, tris);
@@ -909,26 +1002,27 @@ hipError_t ptBuildBvh4(const PtBuildInput &in, PtBuildOutput &out, hipStream_t s
 			if (err == hipSuccess && n > 1 && created != n - 1) err = hipErrorAssert;
 		}
 		// collapse, level by level (host reads the queue length between levels; one-time build)
-		uint32_t init[4] = { 1u, 0u, 0u, 0u };
+		uint32_t init[4] = { 0u, 0u, 0u, 0u };
 		TRY(hipMemcpyAsync(counters, init, sizeof(init), hipMemcpyHostToDevice, stream));
 		CollapseTask root = { rootNode, 0u };
 		TRY(hipMemcpyAsync(taskA, &root, sizeof(root), hipMemcpyHostToDevice, stream));
 		uint32_t nIn = 1;
+		nodeCount = 1;
 		CollapseTask *tin = taskA, *tout = taskB;
 		while (err == hipSuccess && nIn > 0)
 		{
 			++depth;
 			k_collapse_level<<<divUp(nIn, kBlock), kBlock, 0, stream>>>(tin, nIn, tout, counters + 2, (int)n, children,
 			                                                          ploc ? nullptr : range, subCount, boxes, vin, boxMode,
-			                                                          leafPrim, nodes, counters, counters + 1, leafMax,
+			                                                          leafPrim, nodes, nodeCount, counters + 1, leafMax,
 			                                                          in.nodeBase);
 			uint32_t h[4];
 			err = hipMemcpyAsync(h, counters, sizeof(h), hipMemcpyDeviceToHost, stream);
 			TRY(hipStreamSynchronize(stream));
 			if (err != hipSuccess) break;
 			nIn = h[2];
-			nodeCount = h[0];
-			if (h[1] > n || h[0] > n) { err = hipErrorAssert; break; }
+			nodeCount += nIn;
+			if (h[1] > n || nodeCount > n) { err = hipErrorAssert; break; }
 			TRY(hipMemsetAsync(counters + 2, 0, sizeof(uint32_t), stream));
 			CollapseTask *t = tin;
 			tin = tout;
