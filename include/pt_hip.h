@@ -128,6 +128,14 @@ int pt_upload_scene(pt_ctx *ctx, const PtVertex *vertices, uint32_t n_vertices, 
                     uint32_t n_indices, const PtMaterial *materials, uint32_t n_materials,
                     const uint32_t *mat_indices);
 
+/* Diffuse map of the scene (BASELINE config 3 "textured").  No counterpart in the reference's
+ * shaders: it ships textures/viking_room.png and carries Vertex::texCoord (main.cpp:1166-1176, V flipped) through to
+ * raytrace.rchit but never samples it.  Defined here: hitValue (raytrace.rchit:54) = material diffuse x texel, texel =
+ * bilinear, repeat-addressed lookup at the barycentrically interpolated texCoord in the sRGB-decoded image
+ * (pt_srgb8_to_linear), row 0 = v 0.  One map per scene (the reference has one Model); rgba8 = NULL, w = h = 0
+ * removes it.  May be called at any time before a frame; pt_upload_scene keeps it. */
+int pt_set_texture(pt_ctx *ctx, const uint8_t *rgba8, uint32_t width, uint32_t height);
+
 #define PT_ACCEL_BVH4 0         /* LBVH (Morton + LDS radix sort) collapsed to a quantised BVH4 */
 #define PT_ACCEL_BRUTE_FORCE 1  /* no hierarchy: every ray tests every triangle (parity/debug mode) */
 #define PT_ACCEL_BVH4_PLOC 2    /* same sort, BVH2 by parallel locally-ordered clustering (radius 16), same BVH4 */
@@ -268,6 +276,15 @@ int pt_write_ppm(const char *path, const uint8_t *rgba8, uint32_t width, uint32_
 /* 8-bit RGBA PNG (stored deflate blocks, sRGB chunk) of what the sRGB swapchain would show
  * (VulkanSwapchain.cpp:8, shaders/post.frag:9-13): feed it pt_read_image_srgb8's output. */
 int pt_write_png(const char *path, const uint8_t *rgba8, uint32_t width, uint32_t height);
+
+/* stb_image's role in the reference's lineage (external/stb, textures/viking_room.png): decodes an 8-bit
+ * non-interlaced PNG (grey, grey+alpha, RGB, RGBA, palette) to RGBA8 with an own inflate.  *out_rgba8 is
+ * malloc'ed: release it with pt_free. */
+int pt_load_png(const char *path, uint8_t **out_rgba8, uint32_t *width, uint32_t *height);
+void pt_free(void *p);
+/* IEC 61966-2-1 decode of n 8-bit values: c = b/255; c <= 0.04045 ? c/12.92 : pow((c+0.055)/1.055, 2.4), evaluated
+ * in double and rounded once to float (a 256-entry table). */
+void pt_srgb8_to_linear(const uint8_t *srgb8, uint32_t n, float *out);
 
 #ifdef __cplusplus
 }

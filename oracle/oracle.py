@@ -16,7 +16,8 @@ NONE = 0xFFFFFFFF
 class Scene(C.Structure):
     _fields_ = [("verts", C.c_void_p), ("nVerts", C.c_uint32), ("indices", C.c_void_p), ("nIdx", C.c_uint32),
                 ("materials", C.c_void_p), ("nMat", C.c_uint32), ("matIdx", C.c_void_p),
-                ("instances", C.c_void_p), ("nInst", C.c_uint32)]
+                ("instances", C.c_void_p), ("nInst", C.c_uint32),
+                ("texture", C.c_void_p), ("texW", C.c_uint32), ("texH", C.c_uint32)]
 
 
 class Params(C.Structure):
@@ -91,6 +92,7 @@ def _bind(L):
     L.pto_morton_codes.argtypes = [C.POINTER(Scene), vp, vp, vp]
     L.pto_morton_order.argtypes = [vp, u32, vp]
     L.pto_srgb8.argtypes = [vp, u32, vp]
+    L.pto_sample_texture.argtypes = [vp, u32, u32, f32, f32, vp]
     L.pto_max_threads.restype = C.c_int
     return L
 
@@ -171,7 +173,7 @@ def instance_world_to_object(o2w):
 class OracleScene:
     """Holds the reference-layout buffers (Vertex 44 B, Material 24 B) and an optional BVH."""
 
-    def __init__(self, vertices, indices, materials, mat_indices, use_bvh=None, instances=None):
+    def __init__(self, vertices, indices, materials, mat_indices, use_bvh=None, instances=None, texture=None):
         self.vertices = np.ascontiguousarray(vertices, dtype=np.float32).reshape(-1, 11)
         self.indices = np.ascontiguousarray(indices, dtype=np.uint32).reshape(-1)
         self.materials = np.ascontiguousarray(materials, dtype=np.float32).reshape(-1, 6)
@@ -190,6 +192,14 @@ class OracleScene:
                        _p(self.materials), self.materials.shape[0], _p(self.mat_indices),
                        _p(self.instances) if self.instances is not None else None,
                        0 if self.instances is None else self.instances.shape[0])
+        # texture: (H, W, 4) uint8 sRGB diffuse map -> linear float texels (IEC 61966-2-1, evaluated in double)
+        self.texture = None
+        if texture is not None:
+            t = np.ascontiguousarray(texture, dtype=np.uint8)
+            assert t.ndim == 3 and t.shape[2] == 4
+            self.texture = np.ascontiguousarray(srgb8_to_linear_lut()[t])
+            self.texture[..., 3] = t[..., 3].astype(np.float32) / np.float32(255.0)
+            self.c.texture, self.c.texW, self.c.texH = _p(self.texture).value, t.shape[1], t.shape[0]
         if use_bvh is None:
             use_bvh = self.indices.size // 3 > 64
         self.bvh = lib().pto_bvh_build(C.byref(self.c)) if use_bvh else None
@@ -273,6 +283,19 @@ def camera_ray(inv_view, inv_proj, W, H, px, py, jx=0.5, jy=0.5):
     ip = np.ascontiguousarray(inv_proj, dtype=np.float32)
     lib().pto_camera_ray(_p(iv), _p(ip), W, H, px, py, np.float32(jx), np.float32(jy), _p(o), _p(d))
     return o, d
+
+
+def srgb8_to_linear_lut():
+    """256-entry sRGB decode table: c = i/255; c <= 0.04045 ? c/12.92 : ((c+0.055)/1.055)**2.4 in double, one rounding to float."""
+    c = np.arange(256, dtype=np.float64) / 255.0
+    return np.where(c <= 0.04045, c / 12.92, ((c + 0.055) / 1.055) ** 2.4).astype(np.float32)
+
+
+def sample_texture(texture_linear, u, v):
+    t = np.ascontiguousarray(texture_linear, dtype=np.float32)
+    out = np.zeros(3, dtype=np.float32)
+    lib().pto_sample_texture(_p(t), t.shape[1], t.shape[0], C.c_float(u), C.c_float(v), _p(out))
+    return out
 
 
 def srgb8(rgba):

@@ -282,7 +282,32 @@ typedef struct
 	 * world-to-object 3x4 row-major (glm::inverse of the 4x4, computed by the caller with pto_inverse4). */
 	const float *instances;
 	uint32_t nInst;
+	/* Diffuse map (no counterpart in the reference's shaders, which carry Vertex::texCoord
+	 * to raytrace.rchit but never sample textures/viking_room.png): texW x texH linear RGBA float texels, row 0 =
+	 * v 0; NULL = none.  hitValue = material diffuse x pto_sample_texture(interpolated texCoord). */
+	const float *texture;
+	uint32_t texW, texH;
 } PtoScene;
+
+/* Repeat addressing, bilinear filter; every step in fp32 in exactly this order (this build's definition of the
+ * lookup; the device's pt_sample_texture is the same expression tree). */
+void pto_sample_texture(const float *tex, uint32_t w, uint32_t h, float u, float v, float out[3])
+{
+	float su = u - floorf(u), sv = v - floorf(v);
+	float x = su * (float)w - 0.5f, y = sv * (float)h - 0.5f;
+	float x0f = floorf(x), y0f = floorf(y);
+	float fx = x - x0f, fy = y - y0f;
+	int ix0 = (int)x0f, iy0 = (int)y0f;
+	int ix1 = ix0 + 1, iy1 = iy0 + 1;
+	if (ix0 < 0) ix0 += (int)w;
+	if (iy0 < 0) iy0 += (int)h;
+	if (ix1 >= (int)w) ix1 -= (int)w;
+	if (iy1 >= (int)h) iy1 -= (int)h;
+	const float *t00 = tex + 4 * ((size_t)iy0 * w + ix0), *t10 = tex + 4 * ((size_t)iy0 * w + ix1);
+	const float *t01 = tex + 4 * ((size_t)iy1 * w + ix0), *t11 = tex + 4 * ((size_t)iy1 * w + ix1);
+	float gx = 1.0f - fx, gy = 1.0f - fy;
+	for (int k = 0; k < 3; ++k) out[k] = (t00[k] * gx + t10[k] * fx) * gy + (t01[k] * gx + t11[k] * fx) * fy;
+}
 
 typedef struct
 {
@@ -661,6 +686,12 @@ static inline int closest_hit(const PtoScene *sc, const PtoHit *h, uint32_t inst
 	o[0] = P[0]; o[1] = P[1]; o[2] = P[2];
 	emission[0] = mat[3]; emission[1] = mat[4]; emission[2] = mat[5];
 	hitValue[0] = mat[0]; hitValue[1] = mat[1]; hitValue[2] = mat[2];
+	if (sc->texture)
+	{
+		float tu = (v0[9] * bx + v1[9] * by) + v2[9] * bz, tv = (v0[10] * bx + v1[10] * by) + v2[10] * bz, tx[3];
+		pto_sample_texture(sc->texture, sc->texW, sc->texH, tu, tv, tx);
+		for (int k = 0; k < 3; ++k) hitValue[k] = hitValue[k] * tx[k];
+	}
 	return !((mat[3] + mat[4]) + mat[5] > 0.0f);
 }
 

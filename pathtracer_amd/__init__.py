@@ -2,8 +2,8 @@
 clarlzx/PathTracer.  The product is the C-ABI library libpt_hip.so (include/pt_hip.h); this
 package is the thin Python host mirror used by the tests and bench.py."""
 from .api import (HipRaytracing, PathTracerError, Scene, load_obj, look_at, perspective, inverse4, reference_camera,
-                  write_png, write_ppm, write_pfm)
+                  write_png, write_ppm, write_pfm, load_png, srgb8_to_linear)
 from . import scenes
 
-__all__ = ["write_png", "write_ppm", "write_pfm", "HipRaytracing", "PathTracerError", "Scene", "load_obj", "look_at", "perspective", "inverse4",
+__all__ = ["load_png", "srgb8_to_linear", "write_png", "write_ppm", "write_pfm", "HipRaytracing", "PathTracerError", "Scene", "load_obj", "look_at", "perspective", "inverse4",
            "reference_camera", "scenes"]

@@ -82,6 +82,26 @@ def load_obj(path: str) -> Scene:
         L.pt_scene_free(h)
 
 
+def load_png(path: str) -> np.ndarray:
+    """stb_image's role: 8-bit non-interlaced PNG -> (H, W, 4) uint8 RGBA."""
+    L = _lib.lib()
+    ptr, w, h = C.c_void_p(), C.c_uint32(), C.c_uint32()
+    rc = L.pt_load_png(os.fsencode(path), C.byref(ptr), C.byref(w), C.byref(h))
+    if rc != 0:
+        raise PathTracerError(rc, (L.pt_last_error(None) or b"").decode())
+    try:
+        return np.ctypeslib.as_array(C.cast(ptr, C.POINTER(C.c_uint8)), shape=(h.value, w.value, 4)).copy()
+    finally:
+        L.pt_free(ptr)
+
+
+def srgb8_to_linear(values) -> np.ndarray:
+    v = np.ascontiguousarray(values, dtype=np.uint8)
+    out = np.empty(v.shape, dtype=np.float32)
+    _lib.lib().pt_srgb8_to_linear(_p(v), v.size, _p(out))
+    return out
+
+
 def look_at(eye, center, up):
     e, c, u = (np.ascontiguousarray(x, dtype=np.float32) for x in (eye, center, up))
     m = np.zeros(16, dtype=np.float32)
@@ -199,6 +219,15 @@ class HipRaytracing:
         rec["transform"] = t
         rec["mask"] = 0xFF
         self._check(self._L.pt_set_instances(self._ctx, _p(rec), t.shape[0]))
+
+    def setTexture(self, rgba8=None):
+        """Diffuse map (H, W, 4) uint8 sRGB, or None to remove it (pt_set_texture)."""
+        if rgba8 is None:
+            self._check(self._L.pt_set_texture(self._ctx, None, 0, 0))
+            return
+        t = np.ascontiguousarray(rgba8, dtype=np.uint8)
+        assert t.ndim == 3 and t.shape[2] == 4
+        self._check(self._L.pt_set_texture(self._ctx, _p(t), t.shape[1], t.shape[0]))
 
     def buildTlas(self):
         """VulkanRaytracing::buildTlas (VulkanRaytracing.cpp:448-527): one identity instance -- nothing

@@ -41,6 +41,8 @@ struct pt_ctx
 	uint8_t *dPrimEmissive = nullptr;
 	uint32_t nVerts = 0, nIdx = 0, nMats = 0;
 	bool haveScene = false, haveAccel = false, brute = false;
+	float4 *dTexture = nullptr;  // optional diffuse map (pt_set_texture), linear RGBA
+	uint32_t texW = 0, texH = 0;
 	PtBuildOutput accel;
 	double buildMs = 0.0;
 	// two-level scenes (pt_set_instances): 24 floats per instance (object-to-world 3x4, world-to-object 3x4)
@@ -179,6 +181,9 @@ PtSceneDev sceneDev(const pt_ctx *c)
 	s.tris = c->accel.tris;  // plane 0; plane r at tris + r * nTris
 	s.nTris = c->nIdx / 3;
 	s.nNodes = c->accel.nNodes;
+	s.texture = c->dTexture;
+	s.texW = c->texW;
+	s.texH = c->texH;
 	return s;
 }
 
@@ -324,6 +329,7 @@ extern "C" void pt_destroy(pt_ctx *c)
 	for (hipEvent_t e : c->freeEvents) hipEventDestroy(e);
 	freeScene(c);
 	freeQueues(c);
+	hipFree(c->dTexture);
 	hipFree(c->image);
 	hipFree(c->counters);
 	hipFree(c->dStats);
@@ -394,6 +400,28 @@ extern "C" int pt_upload_scene(pt_ctx *c, const PtVertex *v, uint32_t nV, const 
 		PT_HIP(c, hipMemcpy(c->dPrimEmissive, emissive.data(), nTris, hipMemcpyHostToDevice));
 	}
 	c->haveScene = true;
+	return PT_OK;
+}
+
+extern "C" int pt_set_texture(pt_ctx *c, const uint8_t *rgba8, uint32_t w, uint32_t h)
+{
+	if (!c) return fail(nullptr, PT_EINVAL, "null context");
+	if ((rgba8 == nullptr) != (w == 0 || h == 0)) return fail(c, PT_EINVAL, "pt_set_texture: pixels and extent must both be given or both be empty");
+	if (w > 16384 || h > 16384) return fail(c, PT_ELIMIT, "pt_set_texture: %u x %u exceeds 16384 x 16384", w, h);
+	PT_HIP(c, hipSetDevice(c->device));
+	PT_HIP(c, hipStreamSynchronize(c->stream));
+	hipFree(c->dTexture);
+	c->dTexture = nullptr;
+	c->texW = c->texH = 0;
+	if (!rgba8) return PT_OK;
+	const size_t n = (size_t)w * h;
+	std::vector<float> lin(4 * n);
+	pt_srgb8_to_linear(rgba8, (uint32_t)(4 * n), lin.data());
+	for (size_t i = 0; i < n; ++i) lin[4 * i + 3] = (float)rgba8[4 * i + 3] / 255.0f;  // alpha is not a colour (unused by the shading)
+	PT_HIP(c, hipMalloc(&c->dTexture, sizeof(float4) * n));
+	PT_HIP(c, hipMemcpy(c->dTexture, lin.data(), sizeof(float4) * n, hipMemcpyHostToDevice));
+	c->texW = w;
+	c->texH = h;
 	return PT_OK;
 }
 

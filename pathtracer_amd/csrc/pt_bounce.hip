@@ -99,7 +99,8 @@ __global__ void __launch_bounds__(PT_WAVE)
 				float u = V / det, v = W / det;
 				float4 T = thrIn[ridx];
 				const float *mat;
-				pt_shade_hit(sc, prim, u, v, nseed, no, nd, mat);
+				float3x kd;
+				pt_shade_hit(sc, prim, u, v, nseed, no, nd, mat, kd);
 				float ex = mat[3], ey = mat[4], ez = mat[5];
 				if (ex != 0.0f || ey != 0.0f || ez != 0.0f)
 				{
@@ -111,9 +112,9 @@ __global__ void __launch_bounds__(PT_WAVE)
 					rad[nid] = L;
 				}
 				alive = !lastBounce && !((ex + ey) + ez > 0.0f);  // rchit:56-58
-				tx = T.x * mat[0];  // curAttenuation *= hitValue (rgen:79)
-				ty = T.y * mat[1];
-				tz = T.z * mat[2];
+				tx = T.x * kd.x;  // curAttenuation *= hitValue (rgen:79)
+				ty = T.y * kd.y;
+				tz = T.z * kd.z;
 				if (kStats) ++nHits;
 			}
 		}

@@ -279,7 +279,35 @@ struct PtSceneDev
 	const PtTri48 *tris;
 	uint32_t nTris;
 	uint32_t nNodes;
+	// optional diffuse map (pt_set_texture): texW x texH linear RGBA texels, row 0 = v 0; nullptr = none
+	const float4 *texture;
+	uint32_t texW, texH;
 };
+
+// Diffuse map lookup (no counterpart in the reference's shaders, which never sample textures/viking_room.png:
+// SURVEY.md 8(f) row 3).  Repeat addressing, bilinear filter, every step in fp32 in exactly this order (the oracle's
+// pto_sample_texture is the same expression tree).
+__device__ __forceinline__ float3x pt_sample_texture(const float4 *tex, uint32_t w, uint32_t h, float u, float v)
+{
+	float su = u - floorf(u), sv = v - floorf(v);
+	float x = su * (float)w - 0.5f, y = sv * (float)h - 0.5f;
+	float x0f = floorf(x), y0f = floorf(y);
+	float fx = x - x0f, fy = y - y0f;
+	int ix0 = (int)x0f, iy0 = (int)y0f;
+	int ix1 = ix0 + 1, iy1 = iy0 + 1;
+	if (ix0 < 0) ix0 += (int)w;
+	if (iy0 < 0) iy0 += (int)h;
+	if (ix1 >= (int)w) ix1 -= (int)w;
+	if (iy1 >= (int)h) iy1 -= (int)h;
+	const float4 t00 = tex[(size_t)iy0 * w + ix0], t10 = tex[(size_t)iy0 * w + ix1];
+	const float4 t01 = tex[(size_t)iy1 * w + ix0], t11 = tex[(size_t)iy1 * w + ix1];
+	const float gx = 1.0f - fx, gy = 1.0f - fy;
+	float3x r;
+	r.x = (t00.x * gx + t10.x * fx) * gy + (t01.x * gx + t11.x * fx) * fy;
+	r.y = (t00.y * gx + t10.y * fx) * gy + (t01.y * gx + t11.y * fx) * fy;
+	r.z = (t00.z * gx + t10.z * fx) * gy + (t01.z * gx + t11.z * fx) * fy;
+	return r;
+}
 
 // ---------------------------------------------------------------------- closest hit ----
 // raytrace.rchit:24-59 for one hit.  Returns the new ray, updates seed; mat = material record.
@@ -287,14 +315,23 @@ struct PtSceneDev
 // row-major): rchit:45-46 -- worldHitPos = vec3(gl_ObjectToWorldEXT * vec4(localHitPos, 1)) in glm's association
 // (c0*x + c1*y) + (c2*z + c3*1); worldHitNormal = normalize(vec3(localHitNormal * gl_WorldToObjectEXT)), a row
 // vector times the matrix.  xf == nullptr is the reference's single identity instance (no transform arithmetic).
+// kd = hitValue of rchit:54 (the material's diffuse colour, times the diffuse map when the scene has one).
 __device__ __forceinline__ void pt_shade_hit(const PtSceneDev &sc, uint32_t prim, float u, float v, uint32_t &seed,
-                                         float3x &o, float3x &d, const float *&mat, const float *xf = nullptr)
+                                         float3x &o, float3x &d, const float *&mat, float3x &kd,
+                                         const float *xf = nullptr)
 {
 	mat = sc.materials[sc.matIndices[prim]].diffuse;
+	kd = { mat[0], mat[1], mat[2] };
 	const float *v0 = sc.vertices[sc.indices[3 * (size_t)prim + 0]].pos;
 	const float *v1 = sc.vertices[sc.indices[3 * (size_t)prim + 1]].pos;
 	const float *v2 = sc.vertices[sc.indices[3 * (size_t)prim + 2]].pos;
 	float bx = (1.0f - u) - v, by = u, bz = v;
+	if (sc.texture)
+	{
+		float tu = (v0[9] * bx + v1[9] * by) + v2[9] * bz, tv = (v0[10] * bx + v1[10] * by) + v2[10] * bz;
+		float3x tx = pt_sample_texture(sc.texture, sc.texW, sc.texH, tu, tv);
+		kd = { kd.x * tx.x, kd.y * tx.y, kd.z * tx.z };
+	}
 	float3x N, P;
 	N.x = (v0[3] * bx + v1[3] * by) + v2[3] * bz;
 	N.y = (v0[4] * bx + v1[4] * by) + v2[4] * bz;

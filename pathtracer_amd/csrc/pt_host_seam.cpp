@@ -18,6 +18,7 @@
 #include "../../include/pt_hip.h"
 
 #include <cmath>
+#include <cstdlib>
 #include <cstdio>
 #include <cstring>
 #include <fstream>
@@ -783,4 +784,325 @@ extern "C" int pt_write_png(const char *path, const uint8_t *rgba8, uint32_t w, 
 		return PT_EIO;
 	}
 	return PT_OK;
+}
+
+// ------------------------------------------------------------------------------ PNG reader ----
+// What stb_image does for the reference's lineage (textures/viking_room.png).  Own inflate (RFC 1951: stored,
+// fixed and dynamic Huffman blocks, canonical codes decoded bit by bit through count/symbol tables) + PNG
+// unfiltering (RFC 2083 filters 0-4).  8-bit samples, non-interlaced; colour types 0, 2, 3, 4, 6.
+namespace
+{
+struct BitReader
+{
+	const uint8_t *p;
+	size_t n, pos = 0;
+	uint32_t acc = 0;
+	int cnt = 0;
+	bool bad = false;
+	uint32_t bits(int k)
+	{
+		while (cnt < k)
+		{
+			if (pos >= n)
+			{
+				bad = true;
+				return 0;
+			}
+			acc |= (uint32_t)p[pos++] << cnt;
+			cnt += 8;
+		}
+		uint32_t v = acc & ((k < 32 ? (1u << k) : 0u) - 1u);
+		acc >>= k;
+		cnt -= k;
+		return v;
+	}
+};
+
+struct Huffman
+{
+	uint16_t count[16];
+	uint16_t symbol[288];
+	// canonical code from the code lengths; false if the lengths over-subscribe the code space
+	bool build(const uint8_t *len, int n)
+	{
+		memset(count, 0, sizeof(count));
+		for (int i = 0; i < n; ++i) ++count[len[i]];
+		int left = 1;
+		for (int l = 1; l < 16; ++l)
+		{
+			left = (left << 1) - count[l];
+			if (left < 0) return false;
+		}
+		uint16_t offs[16];
+		offs[1] = 0;
+		for (int l = 1; l < 15; ++l) offs[l + 1] = (uint16_t)(offs[l] + count[l]);
+		for (int i = 0; i < n; ++i)
+			if (len[i]) symbol[offs[len[i]]++] = (uint16_t)i;
+		return true;
+	}
+	int decode(BitReader &br) const
+	{
+		int code = 0, first = 0, index = 0;
+		for (int l = 1; l < 16; ++l)
+		{
+			code |= (int)br.bits(1);
+			if (br.bad) return -1;
+			int c = count[l];
+			if (code - c < first) return symbol[index + (code - first)];
+			index += c;
+			first = (first + c) << 1;
+			code <<= 1;
+		}
+		return -1;
+	}
+};
+
+bool inflateBlocks(const uint8_t *src, size_t n, std::vector<uint8_t> &out)
+{
+	static const uint16_t lenBase[29] = { 3, 4, 5, 6, 7, 8, 9, 10, 11, 13, 15, 17, 19, 23, 27, 31, 35, 43, 51, 59, 67, 83, 99, 115, 131, 163, 195, 227, 258 };
+	static const uint8_t lenExtra[29] = { 0, 0, 0, 0, 0, 0, 0, 0, 1, 1, 1, 1, 2, 2, 2, 2, 3, 3, 3, 3, 4, 4, 4, 4, 5, 5, 5, 5, 0 };
+	static const uint16_t distBase[30] = { 1, 2, 3, 4, 5, 7, 9, 13, 17, 25, 33, 49, 65, 97, 129, 193, 257, 385, 513, 769, 1025, 1537, 2049, 3073, 4097, 6145, 8193, 12289, 16385, 24577 };
+	static const uint8_t distExtra[30] = { 0, 0, 0, 0, 1, 1, 2, 2, 3, 3, 4, 4, 5, 5, 6, 6, 7, 7, 8, 8, 9, 9, 10, 10, 11, 11, 12, 12, 13, 13 };
+	static const uint8_t clOrder[19] = { 16, 17, 18, 0, 8, 7, 9, 6, 10, 5, 11, 4, 12, 3, 13, 2, 14, 1, 15 };
+	BitReader br{ src, n };
+	for (;;)
+	{
+		const uint32_t final = br.bits(1), type = br.bits(2);
+		if (br.bad || type == 3) return false;
+		if (type == 0)
+		{
+			br.acc = 0;
+			br.cnt = 0;  // to the next byte boundary
+			if (br.pos + 4 > n) return false;
+			const uint32_t len = src[br.pos] | (src[br.pos + 1] << 8), nlen = src[br.pos + 2] | (src[br.pos + 3] << 8);
+			br.pos += 4;
+			if ((len ^ 0xFFFFu) != nlen || br.pos + len > n) return false;
+			out.insert(out.end(), src + br.pos, src + br.pos + len);
+			br.pos += len;
+		}
+		else
+		{
+			Huffman lit, dist;
+			uint8_t lens[320];
+			if (type == 1)
+			{
+				int i = 0;
+				for (; i < 144; ++i) lens[i] = 8;
+				for (; i < 256; ++i) lens[i] = 9;
+				for (; i < 280; ++i) lens[i] = 7;
+				for (; i < 288; ++i) lens[i] = 8;
+				lit.build(lens, 288);
+				for (i = 0; i < 30; ++i) lens[i] = 5;
+				dist.build(lens, 30);
+			}
+			else
+			{
+				const int nlen = (int)br.bits(5) + 257, ndist = (int)br.bits(5) + 1, ncode = (int)br.bits(4) + 4;
+				if (br.bad || nlen > 286 || ndist > 30) return false;
+				uint8_t cl[19] = { 0 };
+				for (int i = 0; i < ncode; ++i) cl[clOrder[i]] = (uint8_t)br.bits(3);
+				Huffman clh;
+				if (br.bad || !clh.build(cl, 19)) return false;
+				int i = 0;
+				while (i < nlen + ndist)
+				{
+					int sym = clh.decode(br);
+					if (sym < 0) return false;
+					if (sym < 16) lens[i++] = (uint8_t)sym;
+					else
+					{
+						uint8_t prev = 0;
+						int rep;
+						if (sym == 16)
+						{
+							if (i == 0) return false;
+							prev = lens[i - 1];
+							rep = 3 + (int)br.bits(2);
+						}
+						else if (sym == 17) rep = 3 + (int)br.bits(3);
+						else rep = 11 + (int)br.bits(7);
+						if (br.bad || i + rep > nlen + ndist) return false;
+						while (rep--) lens[i++] = prev;
+					}
+				}
+				if (lens[256] == 0 || !lit.build(lens, nlen) || !dist.build(lens + nlen, ndist)) return false;
+			}
+			for (;;)
+			{
+				int sym = lit.decode(br);
+				if (sym < 0) return false;
+				if (sym < 256) out.push_back((uint8_t)sym);
+				else if (sym == 256) break;
+				else
+				{
+					sym -= 257;
+					if (sym >= 29) return false;
+					const size_t len = lenBase[sym] + br.bits(lenExtra[sym]);
+					const int ds = dist.decode(br);
+					if (ds < 0 || ds >= 30) return false;
+					const size_t d = distBase[ds] + br.bits(distExtra[ds]);
+					if (br.bad || d > out.size()) return false;
+					const size_t from = out.size() - d;
+					for (size_t k = 0; k < len; ++k) out.push_back(out[from + k]);  // may overlap: byte by byte
+				}
+			}
+		}
+		if (final) return !br.bad;
+	}
+}
+
+uint32_t get32be(const uint8_t *p) { return ((uint32_t)p[0] << 24) | ((uint32_t)p[1] << 16) | ((uint32_t)p[2] << 8) | p[3]; }
+}  // namespace
+
+extern "C" void pt_free(void *p) { free(p); }
+
+extern "C" int pt_load_png(const char *path, uint8_t **outRgba, uint32_t *outW, uint32_t *outH)
+{
+	if (!path || !outRgba || !outW || !outH)
+	{
+		g_seamError = "pt_load_png: bad argument";
+		return PT_EINVAL;
+	}
+	*outRgba = nullptr;
+	*outW = *outH = 0;
+	FILE *f = fopen(path, "rb");
+	if (!f)
+	{
+		g_seamError = std::string("pt_load_png: cannot open ") + path;
+		return PT_EIO;
+	}
+	std::vector<uint8_t> file;
+	uint8_t buf[65536];
+	size_t got;
+	while ((got = fread(buf, 1, sizeof(buf), f)) > 0) file.insert(file.end(), buf, buf + got);
+	fclose(f);
+	auto bad = [&](const char *why) {
+		g_seamError = std::string("pt_load_png: ") + path + ": " + why;
+		return PT_EIO;
+	};
+	static const uint8_t sig[8] = { 0x89, 'P', 'N', 'G', 0x0D, 0x0A, 0x1A, 0x0A };
+	if (file.size() < 8 + 25 || memcmp(file.data(), sig, 8) != 0) return bad("not a PNG file");
+	uint32_t w = 0, h = 0;
+	int colour = -1;
+	std::vector<uint8_t> idat, palette, trns;
+	bool end = false;
+	for (size_t at = 8; at + 12 <= file.size() && !end;)
+	{
+		const uint32_t len = get32be(&file[at]);
+		const uint8_t *type = &file[at + 4], *data = &file[at + 8];
+		if (len > file.size() || at + 12 + (size_t)len > file.size()) return bad("truncated chunk");
+		const uint32_t crc = crc32Update(0xFFFFFFFFu, type, 4 + (size_t)len) ^ 0xFFFFFFFFu;
+		if (crc != get32be(data + len)) return bad("chunk CRC mismatch");
+		if (!memcmp(type, "IHDR", 4))
+		{
+			if (len != 13) return bad("bad IHDR");
+			w = get32be(data);
+			h = get32be(data + 4);
+			colour = data[9];
+			if (data[8] != 8) return bad("only 8-bit samples are supported");
+			if (data[10] != 0 || data[11] != 0 || data[12] != 0) return bad("interlaced or non-standard PNG");
+			if (colour != 0 && colour != 2 && colour != 3 && colour != 4 && colour != 6) return bad("bad colour type");
+			if (w == 0 || h == 0 || w > 16384 || h > 16384) return bad("extent out of range (1..16384)");
+		}
+		else if (!memcmp(type, "PLTE", 4)) palette.assign(data, data + len);
+		else if (!memcmp(type, "tRNS", 4)) trns.assign(data, data + len);
+		else if (!memcmp(type, "IDAT", 4)) idat.insert(idat.end(), data, data + len);
+		else if (!memcmp(type, "IEND", 4)) end = true;
+		at += 12 + (size_t)len;
+	}
+	if (colour < 0 || !end || idat.size() < 6) return bad("missing IHDR, IDAT or IEND");
+	if ((idat[0] & 0x0F) != 8 || ((idat[0] << 8) | idat[1]) % 31 != 0 || (idat[1] & 0x20)) return bad("bad zlib header");
+	const int ch = colour == 0 ? 1 : colour == 2 ? 3 : colour == 3 ? 1 : colour == 4 ? 2 : 4;
+	const size_t stride = (size_t)w * ch, rawLen = (stride + 1) * h;
+	std::vector<uint8_t> raw;
+	raw.reserve(rawLen);
+	if (!inflateBlocks(idat.data() + 2, idat.size() - 6, raw) || raw.size() != rawLen) return bad("corrupt deflate stream");
+	uint32_t s1 = 1, s2 = 0;
+	for (size_t i = 0; i < rawLen;)
+	{
+		size_t n = rawLen - i < 5552 ? rawLen - i : 5552;
+		for (size_t k = 0; k < n; ++k)
+		{
+			s1 += raw[i + k];
+			s2 += s1;
+		}
+		s1 %= 65521u;
+		s2 %= 65521u;
+		i += n;
+	}
+	if (((s2 << 16) | s1) != get32be(&idat[idat.size() - 4])) return bad("adler32 mismatch");
+	// unfilter in place (RFC 2083 section 6): a = left, b = up, c = upper left
+	for (uint32_t y = 0; y < h; ++y)
+	{
+		uint8_t *row = &raw[(stride + 1) * y + 1];
+		const uint8_t *up = y ? row - (stride + 1) : nullptr;
+		const int filter = row[-1];
+		if (filter > 4) return bad("bad filter type");
+		for (size_t i = 0; i < stride; ++i)
+		{
+			const int a = i >= (size_t)ch ? row[i - ch] : 0, b = up ? up[i] : 0, c = (up && i >= (size_t)ch) ? up[i - ch] : 0;
+			int pred = 0;
+			if (filter == 1) pred = a;
+			else if (filter == 2) pred = b;
+			else if (filter == 3) pred = (a + b) >> 1;
+			else if (filter == 4)
+			{
+				const int p = a + b - c, pa = abs(p - a), pb = abs(p - b), pc = abs(p - c);
+				pred = (pa <= pb && pa <= pc) ? a : (pb <= pc ? b : c);
+			}
+			row[i] = (uint8_t)(row[i] + pred);
+		}
+	}
+	uint8_t *out = (uint8_t *)malloc((size_t)w * h * 4);
+	if (!out)
+	{
+		g_seamError = "pt_load_png: out of memory";
+		return PT_ENOMEM;
+	}
+	for (uint32_t y = 0; y < h; ++y)
+	{
+		const uint8_t *row = &raw[(stride + 1) * y + 1];
+		uint8_t *dst = out + (size_t)y * w * 4;
+		for (uint32_t x = 0; x < w; ++x, dst += 4)
+		{
+			const uint8_t *s = row + (size_t)x * ch;
+			if (colour == 0) { dst[0] = dst[1] = dst[2] = s[0]; dst[3] = 255; }
+			else if (colour == 2) { dst[0] = s[0]; dst[1] = s[1]; dst[2] = s[2]; dst[3] = 255; }
+			else if (colour == 4) { dst[0] = dst[1] = dst[2] = s[0]; dst[3] = s[1]; }
+			else if (colour == 6) { dst[0] = s[0]; dst[1] = s[1]; dst[2] = s[2]; dst[3] = s[3]; }
+			else
+			{
+				const size_t k = s[0];
+				if (3 * k + 2 >= palette.size())
+				{
+					free(out);
+					return bad("palette index out of range");
+				}
+				dst[0] = palette[3 * k];
+				dst[1] = palette[3 * k + 1];
+				dst[2] = palette[3 * k + 2];
+				dst[3] = k < trns.size() ? trns[k] : 255;
+			}
+		}
+	}
+	*outRgba = out;
+	*outW = w;
+	*outH = h;
+	return PT_OK;
+}
+
+extern "C" void pt_srgb8_to_linear(const uint8_t *srgb8, uint32_t n, float *out)
+{
+	static float lut[256];
+	static bool ready = false;
+	if (!ready)
+	{
+		for (int i = 0; i < 256; ++i)
+		{
+			const double c = (double)i / 255.0;
+			lut[i] = (float)(c <= 0.04045 ? c / 12.92 : pow((c + 0.055) / 1.055, 2.4));
+		}
+		ready = true;
+	}
+	for (uint32_t i = 0; i < n; ++i) out[i] = lut[srgb8[i]];
 }

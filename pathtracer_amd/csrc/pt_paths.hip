@@ -114,7 +114,8 @@ __global__ void __launch_bounds__(PT_WAVE) k_paths(PtPathsArgs a)
 				float4 T = a.state[pq];  // throughput, rng state
 				uint32_t seed = __float_as_uint(T.w);
 				const float *mat;
-				pt_shade_hit(sc, prim, u, v, seed, no, nd, mat,
+				float3x kd;
+				pt_shade_hit(sc, prim, u, v, seed, no, nd, mat, kd,
 				             kInst ? a.instances + 24 * (size_t)sDone[kDoneFields][e] : nullptr);
 				float ex = mat[3], ey = mat[4], ez = mat[5];
 				if (ex != 0.0f || ey != 0.0f || ez != 0.0f)
@@ -128,7 +129,7 @@ __global__ void __launch_bounds__(PT_WAVE) k_paths(PtPathsArgs a)
 				}
 				alive = (int)(depth + 1) < a.maxDepth && !((ex + ey) + ez > 0.0f);  // rgen:61 loop bound, rchit:56-58
 				if (alive)  // curAttenuation *= hitValue (rgen:79)
-					a.state[pq] = make_float4(T.x * mat[0], T.y * mat[1], T.z * mat[2], __uint_as_float(seed));
+					a.state[pq] = make_float4(T.x * kd.x, T.y * kd.y, T.z * kd.z, __uint_as_float(seed));
 				if (kStats) ++nHits;
 			}
 		}

@@ -2,7 +2,8 @@
 // (initVulkan -> loadModel -> buildBlas/buildTlas -> mainLoop{updateUniformBuffer, raytrace})
 // without the window: loads an OBJ, renders N frames, writes the accumulation image.
 //
-//   pt_render scene.obj [-w 800] [-h 600] [-spp 10] [-frames 100] [-depth 20] [-seed 0] [-o out.pfm|out.ppm|out.png]
+//   pt_render scene.obj [-w 800] [-h 600] [-spp 10] [-frames 100] [-depth 20] [-seed 0] [-tex map.png]
+//             [-o out.pfm|out.ppm|out.png]
 //
 // Defaults are the reference's constants (VulkanUtils.h:11-15, raytrace.rgen:22-23).
 #include <chrono>
@@ -30,10 +31,10 @@ int main(int argc, char **argv)
 	pt_ctx *ctx = nullptr;
 	if (argc < 2)
 	{
-		fprintf(stderr, "usage: %s scene.obj [-w W] [-h H] [-spp S] [-frames F] [-depth D] [-seed X] [-o out.pfm|.ppm|.png]\n", argv[0]);
+		fprintf(stderr, "usage: %s scene.obj [-w W] [-h H] [-spp S] [-frames F] [-depth D] [-seed X] [-tex map.png] [-o out.pfm|.ppm|.png]\n", argv[0]);
 		return EXIT_FAILURE;
 	}
-	std::string objPath = argv[1], out = "out.pfm";
+	std::string objPath = argv[1], out = "out.pfm", texPath;
 	uint32_t W = 800, H = 600, seed = 0;
 	int spp = 10, frames = 100, depth = 20;
 	for (int i = 2; i + 1 < argc; i += 2)
@@ -47,6 +48,7 @@ int main(int argc, char **argv)
 		else if (k == "-depth") depth = atoi(v);
 		else if (k == "-seed") seed = (uint32_t)strtoul(v, nullptr, 0);
 		else if (k == "-o") out = v;
+		else if (k == "-tex") texPath = v;
 		else
 		{
 			fprintf(stderr, "unknown option %s\n", k.c_str());
@@ -64,6 +66,15 @@ int main(int argc, char **argv)
 	}
 	CHECK(pt_upload_scene(ctx, pt_scene_vertices(sd), pt_scene_n_vertices(sd), pt_scene_indices(sd), pt_scene_n_indices(sd),
 	                      pt_scene_materials(sd), pt_scene_n_materials(sd), pt_scene_mat_indices(sd)));
+	if (!texPath.empty())
+	{
+		// diffuse map over Vertex::texCoord (the reference ships textures/viking_room.png but never samples it)
+		uint8_t *texels = nullptr;
+		uint32_t tw = 0, th = 0;
+		CHECK(pt_load_png(texPath.c_str(), &texels, &tw, &th));
+		CHECK(pt_set_texture(ctx, texels, tw, th));
+		pt_free(texels);
+	}
 	CHECK(pt_build_accel(ctx, PT_ACCEL_BVH4_PLOC));
 	CHECK(pt_resize(ctx, W, H));
 	float view[16], proj[16];

@@ -286,7 +286,8 @@ __global__ void __launch_bounds__(kBlock)
 					uint32_t id = __float_as_uint(rd.w);
 					float3x o, d;
 					const float *mat;
-					pt_shade_hit(sc, prim, h.y, h.z, seed, o, d, mat);
+					float3x kd;
+					pt_shade_hit(sc, prim, h.y, h.z, seed, o, d, mat, kd);
 					float ex = mat[3], ey = mat[4], ez = mat[5];
 					if (ex != 0.0f || ey != 0.0f || ez != 0.0f)
 					{
@@ -302,7 +303,7 @@ __global__ void __launch_bounds__(kBlock)
 						uint32_t dst = outBase + (uint32_t)__popcll(m & lanesBelow);
 						rayOOut[dst] = make_float4(o.x, o.y, o.z, __uint_as_float(seed));
 						rayDOut[dst] = make_float4(d.x, d.y, d.z, __uint_as_float(id));
-						thrOut[dst] = make_float4(T.x * mat[0], T.y * mat[1], T.z * mat[2], 0.0f);  // rgen:79
+						thrOut[dst] = make_float4(T.x * kd.x, T.y * kd.y, T.z * kd.z, 0.0f);  // rgen:79
 					}
 				}
 			}
