@@ -42,13 +42,18 @@
 #define A_MADU24(i) "v_mad_u32_u24 %" #i ", %" #i ", %8, %9\n"
 #define A_XOR(i) "v_xor_b32 %" #i ", %" #i ", %8\n"
 #define A_MULLO(i) "v_mul_lo_u32 %" #i ", %" #i ", %8\n"
+#define A_FMAMIX(i) "v_fma_mix_f32 %" #i ", %" #i ", %8, %9 op_sel_hi:[1,0,0]\n"
+#define A_FMAMIXHI(i) "v_fma_mix_f32 %" #i ", %" #i ", %8, %9 op_sel:[1,0,0] op_sel_hi:[1,0,0]\n"
+#define A_MAXE32(i) "v_max_f32_e32 %" #i ", %" #i ", %8\n"
+#define A_MAXE64(i) "v_max_f32_e64 %" #i ", %" #i ", %8\n"
+#define A_CVTSDWA(i) "v_cvt_f32_ubyte0_sdwa %" #i ", %" #i " dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_2\n"
 #define A_CNDS(i) "v_cndmask_b32 %" #i ", %" #i ", %8, s[20:21]\n"
 #define A_CNDPAIR(i) "v_cmp_lt_f32 vcc, %" #i ", %9\nv_cndmask_b32 %" #i ", %" #i ", %8, vcc\n"
 #define A_CNDPAIRS(i) "v_cmp_lt_f32 s[20:21], %" #i ", %9\nv_cndmask_b32 %" #i ", %" #i ", %8, s[20:21]\n"
 DEFK(k_fma, A_FMA) DEFK(k_minf, A_MINF) DEFK(k_max3, A_MAX3) DEFK(k_minu, A_MINU) DEFK(k_and, A_AND) DEFK(k_addu, A_ADDU)
 DEFK(k_lshladd, A_LSHLADD) DEFK(k_cvtub, A_CVTUB) DEFK(k_cmp, A_CMP) DEFK(k_cnd, A_CND) DEFK(k_bfe, A_BFE) DEFK(k_mov, A_MOV)
 DEFK(k_mul, A_MUL) DEFK(k_sub, A_SUB) DEFK(k_rcp, A_RCP) DEFK(k_sqrt, A_SQRT) DEFK(k_cvtu, A_CVTU) DEFK(k_med3, A_MED3)
-DEFK(k_cnds, A_CNDS) DEFK(k_cndpair, A_CNDPAIR) DEFK(k_cndpairs, A_CNDPAIRS) DEFK(k_perm, A_PERM) DEFK(k_madu24, A_MADU24) DEFK(k_xor, A_XOR) DEFK(k_mullo, A_MULLO)
+DEFK(k_fmamix, A_FMAMIX) DEFK(k_fmamixhi, A_FMAMIXHI) DEFK(k_maxe32, A_MAXE32) DEFK(k_maxe64, A_MAXE64) DEFK(k_cvtsdwa, A_CVTSDWA) DEFK(k_cnds, A_CNDS) DEFK(k_cndpair, A_CNDPAIR) DEFK(k_cndpairs, A_CNDPAIRS) DEFK(k_perm, A_PERM) DEFK(k_madu24, A_MADU24) DEFK(k_xor, A_XOR) DEFK(k_mullo, A_MULLO)
 typedef void (*kfn)(float *, float, float);
 static void run(const char *name, kfn f, float *d)
 {
@@ -67,6 +72,6 @@ int main()
 	float *d; hipMalloc(&d, 256 * 8 * 256 * 4);
 #define R(x) run(#x, x, d);
 	R(k_fma) R(k_mul) R(k_sub) R(k_minf) R(k_max3) R(k_med3) R(k_minu) R(k_and) R(k_xor) R(k_addu) R(k_lshladd) R(k_madu24) R(k_mullo)
-	R(k_bfe) R(k_perm) R(k_cvtub) R(k_cvtu) R(k_cmp) R(k_cnd) R(k_cnds) R(k_cndpair) R(k_cndpairs) R(k_mov) R(k_rcp) R(k_sqrt)
+	R(k_fmamix) R(k_fmamixhi) R(k_maxe32) R(k_maxe64) R(k_cvtsdwa) R(k_bfe) R(k_perm) R(k_cvtub) R(k_cvtu) R(k_cmp) R(k_cnd) R(k_cnds) R(k_cndpair) R(k_cndpairs) R(k_mov) R(k_rcp) R(k_sqrt)
 	return 0;
 }
