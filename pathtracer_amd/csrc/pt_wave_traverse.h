@@ -38,9 +38,12 @@ __device__ __forceinline__ PtLaneRay pt_prepare_ray(float3x o, float3x d)
 	float dcx = fabsf(d.x) > 1e-30f ? d.x : copysignf(1e-30f, d.x);
 	float dcy = fabsf(d.y) > 1e-30f ? d.y : copysignf(1e-30f, d.y);
 	float dcz = fabsf(d.z) > 1e-30f ? d.z : copysignf(1e-30f, d.z);
-	r.ix = 1.0f / dcx;
-	r.iy = 1.0f / dcy;
-	r.iz = 1.0f / dcz;
+	// v_rcp_f32 (1 ulp), not an IEEE division: the reciprocals only feed the box test, whose far plane carries a
+	// 1e-6 relative slack (8 ulp) for exactly this kind of error; |dc| >= 1e-30 keeps operand and result normal.
+	// Saves three of the six divisions of the staging phase (a division is ~13 average VALU slots).
+	r.ix = __builtin_amdgcn_rcpf(dcx);
+	r.iy = __builtin_amdgcn_rcpf(dcy);
+	r.iz = __builtin_amdgcn_rcpf(dcz);
 	r.kpack = kz | ((r.ix < 0.0f) ? 64u : 0u) | ((r.iy < 0.0f) ? 128u : 0u) | ((r.iz < 0.0f) ? 256u : 0u);
 	r.ox = o.x;
 	r.oy = o.y;
