@@ -79,6 +79,10 @@ typedef struct PtStats
 	uint64_t trav_leaf_visits;  /* leaves entered (lane level) */
 	uint64_t trav_node_steps;   /* wave-level node steps: trav_nodes / (64 * trav_node_steps) = lane utilisation */
 	uint64_t trav_leaf_steps;   /* wave-level leaf steps (persistent pipeline only, like the two above) */
+	/* cmdCompactBlas's log line (VulkanRaytracing.cpp:247-256): bytes of the bottom-level structure (nodes, leaf
+	 * triangles, codes, order) after compaction and as the builder had to size it before knowing the node count */
+	uint64_t accel_bytes;
+	uint64_t accel_bytes_uncompacted;
 } PtStats;
 
 typedef struct pt_ctx pt_ctx;
@@ -140,10 +144,13 @@ int pt_set_texture(pt_ctx *ctx, const uint8_t *rgba8, uint32_t width, uint32_t h
 #define PT_ACCEL_BRUTE_FORCE 1  /* no hierarchy: every ray tests every triangle (parity/debug mode) */
 #define PT_ACCEL_BVH4_PLOC 2    /* same sort, BVH2 by parallel locally-ordered clustering (radius 16), same BVH4 */
 #define PT_ACCEL_LEAF_SIZE(n) ((n) << 8) /* OR into flags: at most n (1..8) triangles per leaf; 0 = default */
+#define PT_ACCEL_NO_COMPACTION 0x1000    /* buildBlas(..., allowCompaction = false), VulkanRaytracing.cpp:150,170 */
 
 /* VulkanRaytracing::buildBlas + buildTlas (VulkanRaytracing.cpp:147-262,448-527): what the
  * Vulkan driver did inside vkCmdBuildAccelerationStructuresKHR.  One BLAS, one identity
- * instance.  Blocks until the structure is built (the reference waits with vkQueueWaitIdle). */
+ * instance.  Blocks until the structure is built (the reference waits with vkQueueWaitIdle).
+ * Compaction (cmdCompactBlas, VulkanRaytracing.cpp:300-380; on by default as allowCompaction is): the node array is
+ * re-allocated at its exact size after the build; PtStats reports both sizes. */
 int pt_build_accel(pt_ctx *ctx, int flags);
 
 /* ---- frame state ---------------------------------------------------------------------- */

@@ -16,6 +16,7 @@ PT_NO_HIT = 0xFFFFFFFF
 PT_ACCEL_BVH4 = 0
 PT_ACCEL_BRUTE_FORCE = 1
 PT_ACCEL_BVH4_PLOC = 2
+PT_ACCEL_NO_COMPACTION = 0x1000
 PT_ACCUM_MEAN = 0
 PT_ACCUM_SUM = 1
 PT_PROFILE_KERNELS = 1
@@ -32,7 +33,7 @@ class PtStats(C.Structure):
                 ("bvh_depth", C.c_uint32), ("bvh_tris", C.c_uint32), ("reserved", C.c_uint32),
                 ("build_ms", C.c_double), ("trav_nodes", C.c_uint64), ("trav_tris", C.c_uint64),
                 ("trav_hits", C.c_uint64), ("trav_leaf_visits", C.c_uint64), ("trav_node_steps", C.c_uint64),
-                ("trav_leaf_steps", C.c_uint64)]
+                ("trav_leaf_steps", C.c_uint64), ("accel_bytes", C.c_uint64), ("accel_bytes_uncompacted", C.c_uint64)]
 
 
 # every symbol include/pt_hip.h declares: name -> (restype, argtypes)

@@ -45,6 +45,7 @@ struct pt_ctx
 	uint32_t texW = 0, texH = 0;
 	PtBuildOutput accel;
 	double buildMs = 0.0;
+	uint64_t accelBytes = 0, accelBytesUncompacted = 0;  // acceleration-structure memory after / before compaction
 	// two-level scenes (pt_set_instances): 24 floats per instance (object-to-world 3x4, world-to-object 3x4)
 	std::vector<float> instances;
 	float *dInstances = nullptr;
@@ -293,7 +294,7 @@ extern "C" pt_ctx *pt_create(int device)
 	if (const char *e = getenv("PT_BOUNCE_WAVES_PER_CU"))
 	{
 		int v = atoi(e);
-		if (v >= 1 && v <= 16) wavesPerCU = v;
+		if (v >= 1 && v <= 32) wavesPerCU = v;
 	}
 	c->cfg.bounceWaves = (uint32_t)c->numCUs * (uint32_t)wavesPerCU;
 	if (const char *e = getenv("PT_FRAMES_PER_LAUNCH"))
@@ -511,7 +512,8 @@ extern "C" int pt_build_accel(pt_ctx *c, int flags)
 	if (!c) return fail(nullptr, PT_EINVAL, "null context");
 	if (!c->haveScene) return fail(c, PT_EINVAL, "pt_build_accel: no scene uploaded");
 	const int mode = flags & 0xFF, leafMax = (flags >> 8) & 0xF;
-	if ((mode != PT_ACCEL_BVH4 && mode != PT_ACCEL_BRUTE_FORCE && mode != PT_ACCEL_BVH4_PLOC) || (flags & ~0xFFF) || leafMax > 8)
+	const bool compact = !(flags & PT_ACCEL_NO_COMPACTION);
+	if ((mode != PT_ACCEL_BVH4 && mode != PT_ACCEL_BRUTE_FORCE && mode != PT_ACCEL_BVH4_PLOC) || (flags & ~0x1FFF) || leafMax > 8)
 		return fail(c, PT_EINVAL, "pt_build_accel: bad flags 0x%x", flags);
 	PT_HIP(c, hipSetDevice(c->device));
 	PT_HIP(c, hipStreamSynchronize(c->stream));
@@ -533,6 +535,29 @@ extern "C" int pt_build_accel(pt_ctx *c, int flags)
 	c->freeEvents.push_back(b);
 	if (e != hipSuccess) return fail(c, PT_EHIP, "pt_build_accel: BVH build failed: %s", hipGetErrorString(e));
 	c->blasNodes = c->accel.nNodes;
+	{
+		// cmdCompactBlas (VulkanRaytracing.cpp:300-380): the builder sizes the node array for the worst case (one wide
+		// node per primitive); copy the nodes actually produced into an exact-size allocation and release the rest
+		const uint64_t nPrims = c->nIdx / 3;
+		const uint64_t fixed = nPrims * (3 * sizeof(PtTri48) + 8);  // leaf triangles (three planes) + codes + order
+		c->accelBytesUncompacted = fixed + nPrims * sizeof(PtNode4);
+		c->accelBytes = c->accelBytesUncompacted;
+		if (compact && c->accel.nNodes && c->accel.nNodes < nPrims)
+		{
+			PtNode4 *exact = nullptr;
+			hipError_t ce = hipMalloc(&exact, sizeof(PtNode4) * (size_t)c->accel.nNodes);
+			if (ce == hipSuccess) ce = hipMemcpy(exact, c->accel.nodes, sizeof(PtNode4) * (size_t)c->accel.nNodes, hipMemcpyDeviceToDevice);
+			if (ce != hipSuccess)
+			{
+				hipFree(exact);
+				freeAccel(c);
+				return fail(c, PT_EHIP, "pt_build_accel: compaction failed: %s", hipGetErrorString(ce));
+			}
+			hipFree(c->accel.nodes);
+			c->accel.nodes = exact;
+			c->accelBytes = fixed + (uint64_t)c->accel.nNodes * sizeof(PtNode4);
+		}
+	}
 	if (c->nInst && !c->brute && c->accel.nNodes)
 	{
 		int rc = buildTopLevel(c, in.builder);
@@ -1059,6 +1084,8 @@ extern "C" int pt_get_stats(pt_ctx *c, PtStats *out)
 	out->bvh_depth = c->accel.depth;
 	out->bvh_tris = c->accel.nTris;
 	out->build_ms = c->buildMs;
+	out->accel_bytes = c->accelBytes;
+	out->accel_bytes_uncompacted = c->accelBytesUncompacted;
 	out->trav_nodes = h[2];
 	out->trav_tris = h[3];
 	out->trav_hits = h[4];

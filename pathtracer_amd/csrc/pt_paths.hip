@@ -37,7 +37,15 @@
 
 namespace
 {
-constexpr int kStackLds = 12;   // traversal stack entries per lane held in LDS; deeper ones spill to global
+#ifndef PT_STACK_LDS
+#define PT_STACK_LDS 12
+#endif
+#ifdef PT_PATHS_WAVES_PER_EU  // tuning builds: ask the compiler for that many waves per SIMD (register budget)
+#define PT_PATHS_OCCUPANCY __attribute__((amdgpu_waves_per_eu(PT_PATHS_WAVES_PER_EU, PT_PATHS_WAVES_PER_EU)))
+#else
+#define PT_PATHS_OCCUPANCY
+#endif
+constexpr int kStackLds = PT_STACK_LDS;   // traversal stack entries per lane held in LDS; deeper ones spill to global
 constexpr int kInFields = 11;   // ox oy oz ix iy iz Sx Sy Sz kpack(kz | signs | depth << 16) q   (+ dx dy dz: two-level)
 constexpr int kDoneFields = 6;  // V W det prim q kpack                                          (+ instance: two-level)
 constexpr int kSaveFields = 7;  // two-level: prepared world ray (ix iy iz Sx Sy Sz kpack) while a lane is inside an instance
@@ -52,7 +60,7 @@ __device__ __forceinline__ uint32_t popc64(unsigned long long m) { return (uint3
 // instance's world-to-object matrix (direction NOT renormalised: t means the same in both spaces), pushes
 // PT_INSTANCE_END and descends into the bottom-level tree; popping the marker restores the world ray.
 template <bool kStats, bool kInst>
-__global__ void __launch_bounds__(PT_WAVE) k_paths(PtPathsArgs a)
+__global__ void __launch_bounds__(PT_WAVE) PT_PATHS_OCCUPANCY k_paths(PtPathsArgs a)
 {
 	__shared__ uint32_t sStack[kStackLds][PT_WAVE];
 	__shared__ uint32_t sIn[kInFields + (kInst ? 3 : 0)][PT_WAVE];

@@ -89,6 +89,9 @@ int main(int argc, char **argv)
 	CHECK(pt_get_stats(ctx, &st));
 	printf("%u triangles, BVH4 %u nodes (build %.3f ms); %d frames x %d spp at %ux%u: %.3f s, %.1f Mrays/s, %.2f spp/px/s\n",
 	       st.bvh_tris, st.bvh_nodes, st.build_ms, frames, spp, W, H, sec, st.rays_total / sec / 1e6, frames * spp / sec);
+	if (st.accel_bytes_uncompacted)  // the reference's log line, VulkanRaytracing.cpp:254-255
+		printf("Reduced size of BLAS by %.1f%% from %llu to %llu\n", 100.0 * (double)(st.accel_bytes_uncompacted - st.accel_bytes) / (double)st.accel_bytes_uncompacted,
+		       (unsigned long long)st.accel_bytes_uncompacted, (unsigned long long)st.accel_bytes);
 	const std::string ext = out.size() > 4 ? out.substr(out.size() - 4) : "";
 	if (ext == ".ppm" || ext == ".png")
 	{

@@ -144,3 +144,21 @@ def test_million_triangle_build_traversal_equals_oracle(rt, pa, O, builder):
     assert (got["prim"] != 0xFFFFFFFF).mean() > 0.5
     _, tris = rt.debugReadBvh()
     assert np.array_equal(np.sort(tris["prim"]), np.arange(sc.n_tris, dtype=np.uint32))  # every primitive in exactly one slot
+
+
+def test_compaction_shrinks_the_node_array_and_changes_nothing_else(rt, pa, O):
+    """buildBlas(allowCompaction) of the reference (VulkanRaytracing.cpp:150-256): same tree, same hits, less memory."""
+    from pathtracer_amd._lib import PT_ACCEL_NO_COMPACTION
+    sc = pa.scenes.random_triangles(50000, extent=40.0, edge=1.0)
+    rays = random_rays(50000, (0.0, 0.0, 0.0), (40.0, 40.0, 40.0), seed=3)
+    rt.buildBlas(sc, BUILDERS["lbvh"] | PT_ACCEL_NO_COMPACTION)
+    a, hits_a = rt.stats(), rt.debugTrace(rays)
+    nodes_a, _ = rt.debugReadBvh()
+    assert a.accel_bytes == a.accel_bytes_uncompacted == sc.n_tris * (64 + 3 * 48 + 8)
+    rt.buildBlas(sc, BUILDERS["lbvh"])
+    b, hits_b = rt.stats(), rt.debugTrace(rays)
+    nodes_b, _ = rt.debugReadBvh()
+    assert b.accel_bytes_uncompacted == a.accel_bytes_uncompacted
+    assert b.accel_bytes == sc.n_tris * (3 * 48 + 8) + b.bvh_nodes * 64 < 0.85 * b.accel_bytes_uncompacted
+    assert np.array_equal(hits_a.view(np.uint32), hits_b.view(np.uint32))
+    assert len(nodes_a) == len(nodes_b) == b.bvh_nodes
