@@ -160,7 +160,9 @@ int pt_build_accel(pt_ctx *ctx, int flags);
 int pt_resize(pt_ctx *ctx, uint32_t width, uint32_t height);
 
 /* PathTracer::updateUniformBuffer (main.cpp:1465-1480): UniformBufferObject.view/.proj.  The
- * two inverses raytrace.rgen:44-46 recomputes per sample are hoisted here (glm algorithm). */
+ * two inverses raytrace.rgen:44-46 recomputes per sample are hoisted here (glm algorithm).
+ * A camera that differs from the current one restarts the accumulation (frame = -1): what updateFrame's comment
+ * promises and its TODO leaves out (VulkanRaytracing.cpp:903-908); setting the same matrices again is a no-op. */
 int pt_set_camera(pt_ctx *ctx, const float view[16], const float proj[16]);
 
 /* The reference's compile-time constants made parameters: MAX_SAMPLES (raytrace.rgen:22,

@@ -664,8 +664,14 @@ extern "C" int pt_set_tile(pt_ctx *c, uint32_t x0, uint32_t y0, uint32_t w, uint
 extern "C" int pt_set_camera(pt_ctx *c, const float view[16], const float proj[16])
 {
 	if (!c || !view || !proj) return fail(c, PT_EINVAL, "pt_set_camera: null argument");
-	pt_inverse4(view, c->cam.invView);
-	pt_inverse4(proj, c->cam.invProj);
+	PtCamera cam;
+	pt_inverse4(view, cam.invView);
+	pt_inverse4(proj, cam.invProj);
+	// VulkanRaytracing::updateFrame's stated intent ("Resets the frame counter if the camera has changed",
+	// VulkanRaytracing.cpp:903-908, left as a TODO there): a different camera restarts the accumulation; the same
+	// matrices again (main.cpp calls updateUniformBuffer every frame) change nothing.
+	if (c->haveCamera && memcmp(&cam, &c->cam, sizeof(cam)) != 0) c->frame = -1;
+	c->cam = cam;
 	c->haveCamera = true;
 	return PT_OK;
 }

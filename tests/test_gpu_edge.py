@@ -162,3 +162,25 @@ def test_checkpoint_resume_is_bit_identical(pa, cornell, tmp_path):
     with pytest.raises(pa.PathTracerError):
         b.loadCheckpoint(str(tmp_path / "bad.ckpt"))
     b.cleanup()
+
+
+def test_camera_change_restarts_accumulation(rt, pa, cornell, ocornell):
+    """VulkanRaytracing::updateFrame: "Resets the frame counter if the camera has changed" (its TODO, built here)."""
+    W, H = 96, 64
+    view, proj = pa.reference_camera(W, H)
+    rt.buildBlas(cornell)
+    rt.resize(W, H)
+    rt.setCamera(view, proj)
+    rt.setParams(spp_per_frame=4, max_depth=6, seed=2)
+    rt.raytrace(2)
+    rt.setCamera(view, proj)  # the per-frame updateUniformBuffer of the reference: same matrices, nothing happens
+    assert rt.frame == 1
+    rt.raytrace(1)
+    want3, _ = ocornell.render(view, proj, W, H, 3, spp_per_frame=4, max_depth=6, seed=2)
+    assert np.array_equal(bits(rt.readImage()), bits(want3))
+    view2 = pa.look_at((0.3, 1.2, 5.5), (0.0, 1.0, 0.0), (0, 1, 0))
+    rt.setCamera(view2, proj)
+    assert rt.frame == -1
+    rt.raytrace(2)
+    want2, _ = ocornell.render(view2, proj, W, H, 2, spp_per_frame=4, max_depth=6, seed=2)
+    assert np.array_equal(bits(rt.readImage()), bits(want2))
