@@ -857,7 +857,8 @@ struct Huffman
 	}
 };
 
-bool inflateBlocks(const uint8_t *src, size_t n, std::vector<uint8_t> &out)
+// maxOut: the caller knows the decoded size (PNG: rows x (stride + 1)); anything longer is a corrupt or hostile stream
+bool inflateBlocks(const uint8_t *src, size_t n, std::vector<uint8_t> &out, size_t maxOut)
 {
 	static const uint16_t lenBase[29] = { 3, 4, 5, 6, 7, 8, 9, 10, 11, 13, 15, 17, 19, 23, 27, 31, 35, 43, 51, 59, 67, 83, 99, 115, 131, 163, 195, 227, 258 };
 	static const uint8_t lenExtra[29] = { 0, 0, 0, 0, 0, 0, 0, 0, 1, 1, 1, 1, 2, 2, 2, 2, 3, 3, 3, 3, 4, 4, 4, 4, 5, 5, 5, 5, 0 };
@@ -876,7 +877,7 @@ bool inflateBlocks(const uint8_t *src, size_t n, std::vector<uint8_t> &out)
 			if (br.pos + 4 > n) return false;
 			const uint32_t len = src[br.pos] | (src[br.pos + 1] << 8), nlen = src[br.pos + 2] | (src[br.pos + 3] << 8);
 			br.pos += 4;
-			if ((len ^ 0xFFFFu) != nlen || br.pos + len > n) return false;
+			if ((len ^ 0xFFFFu) != nlen || br.pos + len > n || out.size() + len > maxOut) return false;
 			out.insert(out.end(), src + br.pos, src + br.pos + len);
 			br.pos += len;
 		}
@@ -931,7 +932,11 @@ bool inflateBlocks(const uint8_t *src, size_t n, std::vector<uint8_t> &out)
 			{
 				int sym = lit.decode(br);
 				if (sym < 0) return false;
-				if (sym < 256) out.push_back((uint8_t)sym);
+				if (sym < 256)
+				{
+					if (out.size() >= maxOut) return false;
+					out.push_back((uint8_t)sym);
+				}
 				else if (sym == 256) break;
 				else
 				{
@@ -941,7 +946,7 @@ bool inflateBlocks(const uint8_t *src, size_t n, std::vector<uint8_t> &out)
 					const int ds = dist.decode(br);
 					if (ds < 0 || ds >= 30) return false;
 					const size_t d = distBase[ds] + br.bits(distExtra[ds]);
-					if (br.bad || d > out.size()) return false;
+					if (br.bad || d > out.size() || out.size() + len > maxOut) return false;
 					const size_t from = out.size() - d;
 					for (size_t k = 0; k < len; ++k) out.push_back(out[from + k]);  // may overlap: byte by byte
 				}
@@ -1016,7 +1021,7 @@ extern "C" int pt_load_png(const char *path, uint8_t **outRgba, uint32_t *outW, 
 	const size_t stride = (size_t)w * ch, rawLen = (stride + 1) * h;
 	std::vector<uint8_t> raw;
 	raw.reserve(rawLen);
-	if (!inflateBlocks(idat.data() + 2, idat.size() - 6, raw) || raw.size() != rawLen) return bad("corrupt deflate stream");
+	if (!inflateBlocks(idat.data() + 2, idat.size() - 6, raw, rawLen) || raw.size() != rawLen) return bad("corrupt deflate stream");
 	uint32_t s1 = 1, s2 = 0;
 	for (size_t i = 0; i < rawLen;)
 	{
