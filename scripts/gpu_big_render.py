@@ -23,7 +23,7 @@ else:
     proj = pa.perspective(math.radians(45.0), W / H, 0.1, 100.0)
 proj[5] *= -1
 rt.uploadScene(sc)
-rt.buildBlas(None, PT_ACCEL_BVH4_PLOC if os.environ.get("BUILDER") == "ploc" else PT_ACCEL_BVH4)
+rt.buildBlas(None, (PT_ACCEL_BVH4_PLOC if os.environ.get("BUILDER") == "ploc" else PT_ACCEL_BVH4) | (int(os.environ.get("LEAF", "0")) << 8))
 rt.resize(W, H); rt.setCamera(view, proj); rt.setParams(spp_per_frame=S, max_depth=D, tmax=1e6, max_frames=0)
 rt.raytrace(1); rt.synchronize(); rt.resetStats(); rt.resetFrame()
 t = time.perf_counter(); rt.raytrace(frames); rt.synchronize(); dt = time.perf_counter() - t
