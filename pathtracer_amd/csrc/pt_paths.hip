@@ -22,6 +22,8 @@
 // wave that processes consecutive items of one group continues the chain in a register, a wave that starts
 // in the middle of a group (claims are not aligned to groups) jumps there with the LCG skip-ahead pair
 // (A^2i, C_2i) from a table the host computes.
+#include <stdlib.h>
+
 #include "pt_trace.h"
 #include "pt_wave_traverse.h"
 
@@ -30,6 +32,9 @@
 #endif
 #ifndef PT_PATHS_MAX_ITEMS
 #define PT_PATHS_MAX_ITEMS 8u
+#endif
+#ifndef PT_LDS_NODES
+#define PT_LDS_NODES 16u  // node arrays up to this size are copied into LDS (1 KB per wave)
 #endif
 #ifndef PT_REFILL_LANES
 #define PT_REFILL_LANES 32
@@ -59,13 +64,22 @@ __device__ __forceinline__ uint32_t popc64(unsigned long long m) { return (uint3
 // a leaf reference is an instance index: the lane saves its prepared world ray in LDS, transforms the ray with the
 // instance's world-to-object matrix (direction NOT renormalised: t means the same in both spaces), pushes
 // PT_INSTANCE_END and descends into the bottom-level tree; popping the marker restores the world ray.
-template <bool kStats, bool kInst>
+template <bool kStats, bool kInst, bool kLdsNodes>
 __global__ void __launch_bounds__(PT_WAVE) PT_PATHS_OCCUPANCY k_paths(PtPathsArgs a)
 {
 	__shared__ uint32_t sStack[kStackLds][PT_WAVE];
 	__shared__ uint32_t sIn[kInFields + (kInst ? 3 : 0)][PT_WAVE];
 	__shared__ uint32_t sDone[kDoneFields + (kInst ? 1 : 0)][kDoneRing];
 	__shared__ uint32_t sSave[kInst ? kSaveFields : 1][PT_WAVE];
+	// tiny scenes (<= PT_LDS_NODES wide nodes, e.g. the Cornell box's 7): a wave-private copy of the node array
+	__shared__ uint4 sNodeMem[kLdsNodes ? PT_LDS_NODES : 1][4];
+	const uint4 (*const sNodes)[4] = kLdsNodes ? sNodeMem : nullptr;
+	if (kLdsNodes)
+	{
+		const uint4 *src = reinterpret_cast<const uint4 *>(a.sc.nodes);
+		for (uint32_t i = threadIdx.x; i < a.sc.nNodes * 4u && i < PT_LDS_NODES * 4u; i += PT_WAVE) sNodeMem[i >> 2][i & 3] = src[i];
+		__syncthreads();
+	}
 
 	const PtSceneDev &sc = a.sc;
 	const int lane = threadIdx.x;
@@ -390,7 +404,7 @@ __global__ void __launch_bounds__(PT_WAVE) PT_PATHS_OCCUPANCY k_paths(PtPathsArg
 		if (doNode && !(cur & PT_LEAF_FLAG))
 		{
 			if (kStats) ++nodeFetches;
-			pt_node_step<kStackLds>(sc, ray, tmin, best, cur, sp, sStack, lane, mySpill, a.spillStride);
+			pt_node_step<kStackLds>(sc, ray, tmin, best, cur, sp, sStack, lane, mySpill, a.spillStride, sNodes);
 		}
 		if (!doNode && (cur & PT_LEAF_FLAG) && cur != PT_TRAVERSAL_DONE)
 		{
@@ -525,15 +539,21 @@ __global__ void __launch_bounds__(256)
 
 void ptLaunchPaths(const PtPathsArgs &args, uint32_t waves, bool stats, hipStream_t s)
 {
+	static const bool ldsOff = getenv("PT_LDS_NODES_OFF") != nullptr;  // A/B knob
 	if (args.nInst)
 	{
-		if (stats) k_paths<true, true><<<waves, PT_WAVE, 0, s>>>(args);
-		else k_paths<false, true><<<waves, PT_WAVE, 0, s>>>(args);
+		if (stats) k_paths<true, true, false><<<waves, PT_WAVE, 0, s>>>(args);
+		else k_paths<false, true, false><<<waves, PT_WAVE, 0, s>>>(args);
+	}
+	else if (args.sc.nNodes && args.sc.nNodes <= PT_LDS_NODES && !ldsOff)
+	{
+		if (stats) k_paths<true, false, true><<<waves, PT_WAVE, 0, s>>>(args);
+		else k_paths<false, false, true><<<waves, PT_WAVE, 0, s>>>(args);
 	}
 	else
 	{
-		if (stats) k_paths<true, false><<<waves, PT_WAVE, 0, s>>>(args);
-		else k_paths<false, false><<<waves, PT_WAVE, 0, s>>>(args);
+		if (stats) k_paths<true, false, false><<<waves, PT_WAVE, 0, s>>>(args);
+		else k_paths<false, false, false><<<waves, PT_WAVE, 0, s>>>(args);
 	}
 }
 

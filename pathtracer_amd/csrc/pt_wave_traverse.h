@@ -51,15 +51,32 @@ __device__ __forceinline__ PtLaneRay pt_prepare_ray(float3x o, float3x d)
 	return r;
 }
 
+// sNodes != nullptr: the whole node array is resident in LDS (tiny scenes, see k_paths): four ds_read_b128 instead of
+// four divergent-address global loads (each of which costs the frame as much as ~10 VALU instructions).
 template <int kStackLds>
 __device__ __forceinline__ void pt_node_step(const PtSceneDev &sc, const PtLaneRay &ray, float tmin, const PtBest &best,
                                              uint32_t &cur, int &sp, uint32_t (*sStack)[PT_WAVE], int lane,
-                                             uint32_t *mySpill, uint32_t spillStride)
+                                             uint32_t *mySpill, uint32_t spillStride,
+                                             const uint4 (*sNodes)[4] = nullptr)
 {
 	const float ox = ray.ox, oy = ray.oy, oz = ray.oz, ix = ray.ix, iy = ray.iy, iz = ray.iz;
 	const uint32_t kpack = ray.kpack;
-	const uint4 *np = reinterpret_cast<const uint4 *>(sc.nodes + cur);
-	uint4 n0 = np[0], n1 = np[1], n2 = np[2], n3 = np[3];
+	uint4 n0, n1, n2, n3;
+	if (sNodes)
+	{
+		n0 = sNodes[cur][0];
+		n1 = sNodes[cur][1];
+		n2 = sNodes[cur][2];
+		n3 = sNodes[cur][3];
+	}
+	else
+	{
+		const uint4 *np = reinterpret_cast<const uint4 *>(sc.nodes + cur);
+		n0 = np[0];
+		n1 = np[1];
+		n2 = np[2];
+		n3 = np[3];
+	}
 	// the entry that is popped if no child is hit; read early so its latency hides under the box tests
 	const bool fastStack = sp <= kStackLds - 3;
 	uint32_t top = sStack[sp - 1 < kStackLds ? sp - 1 : 0][lane];
