@@ -779,7 +779,9 @@ int renderPersistent(pt_ctx *c, int n)
 	while (n > 0)
 	{
 		const uint32_t batch = (uint32_t)((size_t)n < perLaunch ? (size_t)n : perLaunch);
-		rc = ensurePersistent(c, nPadded * batch);
+		// a multi-frame call sizes the buffers for full launches at once, so that a later, longer call (warm-up of 4 frames,
+		// then 64) does not reallocate 8 GB in the middle of a render; frame-by-frame callers keep a one-frame buffer
+		rc = ensurePersistent(c, nPadded * (n > 1 ? perLaunch : (size_t)batch));
 		if (rc) return rc;
 		const uint32_t frame0 = (uint32_t)(c->frame + 1);
 		const uint32_t gframe0 = c->firstFrame + frame0 * c->frameStride;
