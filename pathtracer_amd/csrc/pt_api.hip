@@ -39,6 +39,7 @@ struct pt_ctx
 	uint32_t *dIndices = nullptr, *dMatIdx = nullptr;
 	PtMaterial *dMats = nullptr;
 	uint8_t *dPrimEmissive = nullptr;
+	PtShadeRec *dShade = nullptr;  // per-primitive shading records (pt_device_common.h)
 	uint32_t nVerts = 0, nIdx = 0, nMats = 0;
 	bool haveScene = false, haveAccel = false, brute = false;
 	float4 *dTexture = nullptr;  // optional diffuse map (pt_set_texture), linear RGBA
@@ -142,6 +143,8 @@ void freeScene(pt_ctx *c)
 	hipFree(c->dMats);
 	hipFree(c->dMatIdx);
 	hipFree(c->dPrimEmissive);
+	hipFree(c->dShade);
+	c->dShade = nullptr;
 	c->dVerts = nullptr;
 	c->dIndices = c->dMatIdx = nullptr;
 	c->dMats = nullptr;
@@ -178,6 +181,7 @@ PtSceneDev sceneDev(const pt_ctx *c)
 	s.indices = c->dIndices;
 	s.materials = c->dMats;
 	s.matIndices = c->dMatIdx;
+	s.shade = c->dShade;
 	s.nodes = c->accel.nodes;
 	s.tris = c->accel.tris;  // plane 0; plane r at tris + r * nTris
 	s.nTris = c->nIdx / 3;
@@ -401,6 +405,14 @@ extern "C" int pt_upload_scene(pt_ctx *c, const PtVertex *v, uint32_t nV, const 
 		PT_HIP(c, hipMemcpy(c->dPrimEmissive, emissive.data(), nTris, hipMemcpyHostToDevice));
 	}
 	c->haveScene = true;
+	if (nTris && !getenv("PT_NO_SHADE_RECORDS"))
+	{
+		PT_HIP(c, hipMalloc(&c->dShade, sizeof(PtShadeRec) * (size_t)nTris));
+		PtSceneDev sc = sceneDev(c);
+		sc.nTris = nTris;
+		ptLaunchBuildShadeRecords(sc, c->dShade, c->stream);
+		PT_HIP(c, hipStreamSynchronize(c->stream));
+	}
 	return PT_OK;
 }
 

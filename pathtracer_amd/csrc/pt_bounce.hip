@@ -98,10 +98,9 @@ __global__ void __launch_bounds__(PT_WAVE)
 				uint32_t ridx = sDone[6][e];
 				float u = V / det, v = W / det;
 				float4 T = thrIn[ridx];
-				const float *mat;
-				float3x kd;
-				pt_shade_hit(sc, prim, u, v, nseed, no, nd, mat, kd);
-				float ex = mat[3], ey = mat[4], ez = mat[5];
+				float3x kd, ke;
+				pt_shade_hit(sc, prim, u, v, nseed, no, nd, kd, ke);
+				float ex = ke.x, ey = ke.y, ez = ke.z;
 				if (ex != 0.0f || ey != 0.0f || ez != 0.0f)
 				{
 					// accumDepthHitValue += emission * curAttenuation (rgen:78); one thread owns a path

@@ -269,12 +269,27 @@ struct __attribute__((aligned(16))) PtTri48
 };
 static_assert(sizeof(PtTri48) == 48, "PtTri48 must be 48 bytes");
 
+// Everything raytrace.rchit fetches for one primitive through matIndices -> Material and indices -> 3 x Vertex
+// (rchit:27-37), gathered once at upload into one 96-byte record: six 16-byte loads of one lane instead of ten
+// dependent ones (a divergent-address load in a hot phase costs the frame as much as ~10 VALU instructions,
+// DESIGN.md 5.2).  Same values, so the shading arithmetic is unchanged.  Texture coordinates are not in it:
+// scenes with a diffuse map take the gather path.
+struct __attribute__((aligned(16))) PtShadeRec
+{
+	float pos[3][3];  // v0, v1, v2
+	float nrm[3][3];
+	float kd[3];      // Material::diffuse
+	float ke[3];      // Material::emission
+};
+static_assert(sizeof(PtShadeRec) == 96, "PtShadeRec must be 96 bytes");
+
 struct PtSceneDev
 {
 	const PtVertex *vertices;
 	const uint32_t *indices;
 	const PtMaterial *materials;
 	const uint32_t *matIndices;
+	const PtShadeRec *shade;  // per-primitive shading records (nullptr: gather as raytrace.rchit does)
 	const PtNode4 *nodes;
 	const PtTri48 *tris;
 	uint32_t nTris;
@@ -315,30 +330,49 @@ __device__ __forceinline__ float3x pt_sample_texture(const float4 *tex, uint32_t
 // row-major): rchit:45-46 -- worldHitPos = vec3(gl_ObjectToWorldEXT * vec4(localHitPos, 1)) in glm's association
 // (c0*x + c1*y) + (c2*z + c3*1); worldHitNormal = normalize(vec3(localHitNormal * gl_WorldToObjectEXT)), a row
 // vector times the matrix.  xf == nullptr is the reference's single identity instance (no transform arithmetic).
-// kd = hitValue of rchit:54 (the material's diffuse colour, times the diffuse map when the scene has one).
+// kd = hitValue of rchit:54 (the material's diffuse colour, times the diffuse map when the scene has one), ke = emission.
 __device__ __forceinline__ void pt_shade_hit(const PtSceneDev &sc, uint32_t prim, float u, float v, uint32_t &seed,
-                                         float3x &o, float3x &d, const float *&mat, float3x &kd,
-                                         const float *xf = nullptr)
+                                         float3x &o, float3x &d, float3x &kd, float3x &ke, const float *xf = nullptr)
 {
-	mat = sc.materials[sc.matIndices[prim]].diffuse;
-	kd = { mat[0], mat[1], mat[2] };
-	const float *v0 = sc.vertices[sc.indices[3 * (size_t)prim + 0]].pos;
-	const float *v1 = sc.vertices[sc.indices[3 * (size_t)prim + 1]].pos;
-	const float *v2 = sc.vertices[sc.indices[3 * (size_t)prim + 2]].pos;
 	float bx = (1.0f - u) - v, by = u, bz = v;
-	if (sc.texture)
+	float p0[3], p1[3], p2[3], n0[3], n1[3], n2[3];
+	if (sc.shade && !sc.texture)
 	{
-		float tu = (v0[9] * bx + v1[9] * by) + v2[9] * bz, tv = (v0[10] * bx + v1[10] * by) + v2[10] * bz;
-		float3x tx = pt_sample_texture(sc.texture, sc.texW, sc.texH, tu, tv);
-		kd = { kd.x * tx.x, kd.y * tx.y, kd.z * tx.z };
+		const float4 *r = reinterpret_cast<const float4 *>(sc.shade + prim);
+		const float4 a = r[0], b = r[1], c = r[2], e = r[3], f = r[4], g = r[5];
+		p0[0] = a.x; p0[1] = a.y; p0[2] = a.z; p1[0] = a.w; p1[1] = b.x; p1[2] = b.y; p2[0] = b.z; p2[1] = b.w; p2[2] = c.x;
+		n0[0] = c.y; n0[1] = c.z; n0[2] = c.w; n1[0] = e.x; n1[1] = e.y; n1[2] = e.z; n2[0] = e.w; n2[1] = f.x; n2[2] = f.y;
+		kd = { f.z, f.w, g.x };
+		ke = { g.y, g.z, g.w };
+	}
+	else
+	{
+		const float *mat = sc.materials[sc.matIndices[prim]].diffuse;
+		kd = { mat[0], mat[1], mat[2] };
+		ke = { mat[3], mat[4], mat[5] };
+		const float *v0 = sc.vertices[sc.indices[3 * (size_t)prim + 0]].pos;
+		const float *v1 = sc.vertices[sc.indices[3 * (size_t)prim + 1]].pos;
+		const float *v2 = sc.vertices[sc.indices[3 * (size_t)prim + 2]].pos;
+#pragma unroll
+		for (int k = 0; k < 3; ++k)
+		{
+			p0[k] = v0[k]; p1[k] = v1[k]; p2[k] = v2[k];
+			n0[k] = v0[3 + k]; n1[k] = v1[3 + k]; n2[k] = v2[3 + k];
+		}
+		if (sc.texture)
+		{
+			float tu = (v0[9] * bx + v1[9] * by) + v2[9] * bz, tv = (v0[10] * bx + v1[10] * by) + v2[10] * bz;
+			float3x tx = pt_sample_texture(sc.texture, sc.texW, sc.texH, tu, tv);
+			kd = { kd.x * tx.x, kd.y * tx.y, kd.z * tx.z };
+		}
 	}
 	float3x N, P;
-	N.x = (v0[3] * bx + v1[3] * by) + v2[3] * bz;
-	N.y = (v0[4] * bx + v1[4] * by) + v2[4] * bz;
-	N.z = (v0[5] * bx + v1[5] * by) + v2[5] * bz;
-	P.x = (v0[0] * bx + v1[0] * by) + v2[0] * bz;
-	P.y = (v0[1] * bx + v1[1] * by) + v2[1] * bz;
-	P.z = (v0[2] * bx + v1[2] * by) + v2[2] * bz;
+	N.x = (n0[0] * bx + n1[0] * by) + n2[0] * bz;
+	N.y = (n0[1] * bx + n1[1] * by) + n2[1] * bz;
+	N.z = (n0[2] * bx + n1[2] * by) + n2[2] * bz;
+	P.x = (p0[0] * bx + p1[0] * by) + p2[0] * bz;
+	P.y = (p0[1] * bx + p1[1] * by) + p2[1] * bz;
+	P.z = (p0[2] * bx + p1[2] * by) + p2[2] * bz;
 	if (xf)
 	{
 		const float *w = xf + 12;

@@ -135,11 +135,10 @@ __global__ void __launch_bounds__(PT_WAVE) PT_PATHS_OCCUPANCY k_paths(PtPathsArg
 				float u = V / det, v = W / det;
 				float4 T = a.state[pq];  // throughput, rng state
 				uint32_t seed = __float_as_uint(T.w);
-				const float *mat;
-				float3x kd;
-				pt_shade_hit(sc, prim, u, v, seed, no, nd, mat, kd,
+				float3x kd, ke;
+				pt_shade_hit(sc, prim, u, v, seed, no, nd, kd, ke,
 				             kInst ? a.instances + 24 * (size_t)sDone[kDoneFields][e] : nullptr);
-				float ex = mat[3], ey = mat[4], ez = mat[5];
+				float ex = ke.x, ey = ke.y, ez = ke.z;
 				if (ex != 0.0f || ey != 0.0f || ez != 0.0f)
 				{
 					// accumDepthHitValue += emission * curAttenuation (rgen:78); one thread owns a path

@@ -98,4 +98,5 @@ void ptLaunchDebugRng(uint32_t n, const uint32_t *v0, const uint32_t *v1, uint32
                       uint32_t *outLcg, float *outUnit, hipStream_t s);
 void ptLaunchPackRays(const float *rays, uint32_t n, float4 *rayO, float4 *rayD, hipStream_t s);
 void ptLaunchSetU32(uint32_t *p, uint32_t v, hipStream_t s);
+void ptLaunchBuildShadeRecords(const PtSceneDev &sc, PtShadeRec *out, hipStream_t s);
 void ptLaunchSrgb8(const float4 *image, uint32_t n, void *out, hipStream_t s);

@@ -285,10 +285,9 @@ __global__ void __launch_bounds__(kBlock)
 					uint32_t seed = __float_as_uint(ro.w);
 					uint32_t id = __float_as_uint(rd.w);
 					float3x o, d;
-					const float *mat;
-					float3x kd;
-					pt_shade_hit(sc, prim, h.y, h.z, seed, o, d, mat, kd);
-					float ex = mat[3], ey = mat[4], ez = mat[5];
+					float3x kd, ke;
+					pt_shade_hit(sc, prim, h.y, h.z, seed, o, d, kd, ke);
+					float ex = ke.x, ey = ke.y, ez = ke.z;
 					if (ex != 0.0f || ey != 0.0f || ez != 0.0f)
 					{
 						// accumDepthHitValue += emission * curAttenuation (rgen:78); each path owns rad[id]
@@ -495,6 +494,32 @@ void ptLaunchDebugRng(uint32_t n, const uint32_t *v0, const uint32_t *v1, uint32
 void ptLaunchPackRays(const float *rays, uint32_t n, float4 *rayO, float4 *rayD, hipStream_t s)
 {
 	k_pack_rays<<<divUp(n, 256), 256, 0, s>>>(rays, n, rayO, rayD);
+}
+
+// raytrace.rchit:27-37's fetches, done once per primitive (PtShadeRec, pt_device_common.h)
+__global__ void __launch_bounds__(kBlock) k_build_shade_records(PtSceneDev sc, PtShadeRec *out)
+{
+	uint32_t prim = blockIdx.x * kBlock + threadIdx.x;
+	if (prim >= sc.nTris) return;
+	PtShadeRec r;
+	const float *mat = sc.materials[sc.matIndices[prim]].diffuse;
+	for (int j = 0; j < 3; ++j)
+	{
+		const float *v = sc.vertices[sc.indices[3 * (size_t)prim + j]].pos;
+		for (int k = 0; k < 3; ++k)
+		{
+			r.pos[j][k] = v[k];
+			r.nrm[j][k] = v[3 + k];
+		}
+		r.kd[j] = mat[j];
+		r.ke[j] = mat[3 + j];
+	}
+	out[prim] = r;
+}
+
+void ptLaunchBuildShadeRecords(const PtSceneDev &sc, PtShadeRec *out, hipStream_t s)
+{
+	if (sc.nTris) k_build_shade_records<<<divUp(sc.nTris, kBlock), kBlock, 0, s>>>(sc, out);
 }
 
 void ptLaunchSetU32(uint32_t *p, uint32_t v, hipStream_t s) { k_set_u32<<<1, 1, 0, s>>>(p, v); }
