@@ -60,3 +60,18 @@ def test_product_never_imports_the_oracle():
                     ("import oracle" not in line and "liboracle" not in line and "pt_oracle" not in line
                      and "obj_oracle" not in line) or line.lstrip().startswith(("//", "#", "*"))
                     for line in text.splitlines()), f"{f} references the oracle"
+
+
+def test_create_without_a_gpu_fails_cleanly(pa):
+    """On a machine without a HIP device pt_create returns NULL and says why (no crash, no CPU fallback); with a device it
+    returns a context.  Context-free host-seam calls work either way."""
+    from pathtracer_amd import _lib
+    L = _lib.lib()
+    ctx = L.pt_create(0)
+    if ctx:
+        L.pt_destroy(ctx)
+    else:
+        msg = L.pt_last_error(None).decode()
+        assert "pt_create" in msg and len(msg) > 12
+    view, proj = pa.reference_camera(800, 600)
+    assert view.shape == (16,) and abs(float(view[14]) + 3.5) < 1e-6  # eye at z = 3.5 (main.cpp:1469)
