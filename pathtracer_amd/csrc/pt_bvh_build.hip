@@ -71,8 +71,8 @@ __global__ void __launch_bounds__(kBlock) k_tri_setup(const PtVertex *verts, con
 				if (c > hi[k]) hi[k] = c;
 			}
 		}
-		triLo[i] = make_float4(lo[0], lo[1], lo[2], 0.0f);
-		triHi[i] = make_float4(hi[0], hi[1], hi[2], 0.0f);
+		triLo[2 * (size_t)i] = make_float4(lo[0], lo[1], lo[2], 0.0f);
+		triHi[2 * (size_t)i] = make_float4(hi[0], hi[1], hi[2], 0.0f);
 #pragma unroll
 		for (int k = 0; k < 3; ++k)
 		{
@@ -118,8 +118,8 @@ __global__ void __launch_bounds__(kBlock) k_box_setup(const float4 *inLo, const 
 	uint32_t i = blockIdx.x * kBlock + threadIdx.x;
 	if (i >= n) return;
 	float4 lo = inLo[i], hi = inHi[i];
-	triLo[i] = lo;
-	triHi[i] = hi;
+	triLo[2 * (size_t)i] = lo;
+	triHi[2 * (size_t)i] = hi;
 	float l[3] = { lo.x, lo.y, lo.z }, h[3] = { hi.x, hi.y, hi.z };
 	float amax = 0.0f;
 	for (int k = 0; k < 3; ++k)
@@ -146,7 +146,7 @@ __global__ void __launch_bounds__(kBlock) k_morton(const float4 *triLo, const fl
 {
 	uint32_t i = blockIdx.x * kBlock + threadIdx.x;
 	if (i >= nTris) return;
-	float4 lo = triLo[i], hi = triHi[i];
+	float4 lo = triLo[2 * (size_t)i], hi = triHi[2 * (size_t)i];
 	float c[3] = { (lo.x + hi.x) * 0.5f, (lo.y + hi.y) * 0.5f, (lo.z + hi.z) * 0.5f };
 	uint32_t q[3];
 #pragma unroll
@@ -446,7 +446,7 @@ __global__ void __launch_bounds__(kBlock) k_refit(const float4 *triLo, const flo
 	if (k >= n) return;
 	const float pad = __uint_as_float((unsigned int)bounds[6]) * padScale;  // 2^-18 * max|coord| for triangles
 	uint32_t prim = sortedPrim[k];
-	float4 l4 = triLo[prim], h4 = triHi[prim];
+	float4 l4 = triLo[2 * (size_t)prim], h4 = triHi[2 * (size_t)prim];
 	float lo[3] = { l4.x - pad, l4.y - pad, l4.z - pad }, hi[3] = { h4.x + pad, h4.y + pad, h4.z + pad };
 	int cur = (n - 1) + k;
 	int p = parent[cur];
@@ -750,7 +750,7 @@ __global__ void __launch_bounds__(kBlock) k_ploc_leaves(const float4 *triLo, con
 	if (k >= n) return;
 	const float pad = __uint_as_float((unsigned int)bounds[6]) * padScale;  // as k_refit
 	uint32_t prim = sortedPrim[k];
-	float4 l4 = triLo[prim], h4 = triHi[prim];
+	float4 l4 = triLo[2 * (size_t)prim], h4 = triHi[2 * (size_t)prim];
 	float *b = boxes + 8 * (size_t)((n - 1) + k);
 	b[0] = l4.x - pad; b[1] = l4.y - pad; b[2] = l4.z - pad; b[3] = 0.0f;
 	b[4] = h4.x + pad; b[5] = h4.y + pad; b[6] = h4.z + pad; b[7] = 0.0f;
@@ -894,7 +894,9 @@ hipError_t ptBuildBvh4(const PtBuildInput &in, PtBuildOutput &out, hipStream_t s
 		arenaBytes += (bytes + 255) & ~(size_t)255;
 		return at;
 	};
-	const size_t oTriLo = reserve(sizeof(float4) * n), oTriHi = reserve(sizeof(float4) * n), oBounds = reserve(64);
+	// primitive boxes interleaved (lo, hi) in ONE array: the gathers through the sorted order touch one 32-byte record per
+	// primitive instead of two 16-byte ones in different arrays; the kernels see it as two pointers with a stride of 2
+	const size_t oTriLo = reserve(2 * sizeof(float4) * n), oBounds = reserve(64);
 	const size_t oKeysA = reserve(4 * (size_t)n), oKeysB = reserve(4 * (size_t)n), oValsA = reserve(4 * (size_t)n),
 	             oValsB = reserve(4 * (size_t)n);
 	const size_t oHist = reserve(4 * histLen), oScan = reserve(4 * scanScratchLen(histLen));
@@ -911,7 +913,7 @@ hipError_t ptBuildBvh4(const PtBuildInput &in, PtBuildOutput &out, hipStream_t s
 #define TRY(x)                      \
 	if (err == hipSuccess) err = (x)
 #define AT(T, off) reinterpret_cast<T *>(arena + (off))
-	float4 *triLo = AT(float4, oTriLo), *triHi = AT(float4, oTriHi);
+	float4 *triLo = AT(float4, oTriLo), *triHi = triLo + 1;
 	int *bounds = AT(int, oBounds);
 	uint32_t *keysA = AT(uint32_t, oKeysA), *keysB = AT(uint32_t, oKeysB), *valsA = AT(uint32_t, oValsA),
 	         *valsB = AT(uint32_t, oValsB), *hist = AT(uint32_t, oHist), *scanScratch = AT(uint32_t, oScan);
