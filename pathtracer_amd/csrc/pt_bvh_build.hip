@@ -51,14 +51,18 @@ __device__ __forceinline__ float waveMax(float v)
 }
 
 // bounds[0..2] = centroid min (ordered int), [3..5] = centroid max, [6] = max |coordinate| (float bits)
+// triPos: the three positions of every primitive as one 48-byte record (the layout of a plane-2 leaf triangle without the
+// id), written here where the vertices are gathered anyway in primitive order; k_write_tris then needs ONE gathered
+// record per triangle in leaf order instead of an index triple and three vertices.
 __global__ void __launch_bounds__(kBlock) k_tri_setup(const PtVertex *verts, const uint32_t *indices, uint32_t nTris,
-                                                      float4 *triLo, float4 *triHi, int *bounds)
+                                                      float4 *triLo, float4 *triHi, int *bounds, float4 *triPos)
 {
 	float cmin[3] = { FLT_MAX, FLT_MAX, FLT_MAX }, cmax[3] = { -FLT_MAX, -FLT_MAX, -FLT_MAX };
 	float amax = 0.0f;
 	for (uint32_t i = blockIdx.x * kBlock + threadIdx.x; i < nTris; i += gridDim.x * kBlock)
 	{
 		float lo[3] = { INFINITY, INFINITY, INFINITY }, hi[3] = { -INFINITY, -INFINITY, -INFINITY };
+		float q[3][3];
 #pragma unroll
 		for (int j = 0; j < 3; ++j)
 		{
@@ -67,10 +71,14 @@ __global__ void __launch_bounds__(kBlock) k_tri_setup(const PtVertex *verts, con
 			for (int k = 0; k < 3; ++k)
 			{
 				float c = p[k];
+				q[j][k] = c;
 				if (c < lo[k]) lo[k] = c;
 				if (c > hi[k]) hi[k] = c;
 			}
 		}
+		triPos[3 * (size_t)i + 0] = make_float4(q[0][0], q[0][1], q[0][2], q[1][0]);
+		triPos[3 * (size_t)i + 1] = make_float4(q[1][1], q[1][2], q[2][0], q[2][1]);
+		triPos[3 * (size_t)i + 2] = make_float4(q[2][2], 0.0f, 0.0f, 0.0f);
 		triLo[2 * (size_t)i] = make_float4(lo[0], lo[1], lo[2], 0.0f);
 		triHi[2 * (size_t)i] = make_float4(hi[0], hi[1], hi[2], 0.0f);
 #pragma unroll
@@ -704,16 +712,14 @@ __global__ void __launch_bounds__(kBlock)
 // ((r+1)%3, (r+2)%3, r) so that the watertight test of a ray whose dominant axis is r reads them without per-lane
 // selects (plane 2 is the identity).  One thread per slot: three 16-byte stores per plane, consecutive lanes write
 // consecutive 48-byte records.
-__global__ void __launch_bounds__(kBlock) k_write_tris(const uint32_t *leafPrim, uint32_t n, const PtVertex *verts,
-                                                       const uint32_t *indices, PtTri48 *tris)
+__global__ void __launch_bounds__(kBlock) k_write_tris(const uint32_t *leafPrim, uint32_t n, const float4 *triPos,
+                                                       PtTri48 *tris)
 {
 	uint32_t j = blockIdx.x * kBlock + threadIdx.x;
 	if (j >= n) return;
 	const uint32_t prim = leafPrim[j];
-	const float *p0 = verts[indices[3 * (size_t)prim + 0]].pos;
-	const float *p1 = verts[indices[3 * (size_t)prim + 1]].pos;
-	const float *p2 = verts[indices[3 * (size_t)prim + 2]].pos;
-	const float a[3] = { p0[0], p0[1], p0[2] }, b[3] = { p1[0], p1[1], p1[2] }, c[3] = { p2[0], p2[1], p2[2] };
+	const float4 r0 = triPos[3 * (size_t)prim + 0], r1 = triPos[3 * (size_t)prim + 1], r2 = triPos[3 * (size_t)prim + 2];
+	const float a[3] = { r0.x, r0.y, r0.z }, b[3] = { r0.w, r1.x, r1.y }, c[3] = { r1.z, r1.w, r2.x };
 #pragma unroll
 	for (int r = 0; r < 3; ++r)
 	{
@@ -897,6 +903,7 @@ hipError_t ptBuildBvh4(const PtBuildInput &in, PtBuildOutput &out, hipStream_t s
 	// primitive boxes interleaved (lo, hi) in ONE array: the gathers through the sorted order touch one 32-byte record per
 	// primitive instead of two 16-byte ones in different arrays; the kernels see it as two pointers with a stride of 2
 	const size_t oTriLo = reserve(2 * sizeof(float4) * n), oBounds = reserve(64);
+	const size_t oTriPos = reserve(boxMode ? 0 : 3 * sizeof(float4) * (size_t)n);
 	const size_t oKeysA = reserve(4 * (size_t)n), oKeysB = reserve(4 * (size_t)n), oValsA = reserve(4 * (size_t)n),
 	             oValsB = reserve(4 * (size_t)n);
 	const size_t oHist = reserve(4 * histLen), oScan = reserve(4 * scanScratchLen(histLen));
@@ -913,7 +920,7 @@ hipError_t ptBuildBvh4(const PtBuildInput &in, PtBuildOutput &out, hipStream_t s
 #define TRY(x)                      \
 	if (err == hipSuccess) err = (x)
 #define AT(T, off) reinterpret_cast<T *>(arena + (off))
-	float4 *triLo = AT(float4, oTriLo), *triHi = triLo + 1;
+	float4 *triLo = AT(float4, oTriLo), *triHi = triLo + 1, *triPos = AT(float4, oTriPos);
 	int *bounds = AT(int, oBounds);
 	uint32_t *keysA = AT(uint32_t, oKeysA), *keysB = AT(uint32_t, oKeysB), *valsA = AT(uint32_t, oValsA),
 	         *valsB = AT(uint32_t, oValsB), *hist = AT(uint32_t, oHist), *scanScratch = AT(uint32_t, oScan);
@@ -945,7 +952,7 @@ hipError_t ptBuildBvh4(const PtBuildInput &in, PtBuildOutput &out, hipStream_t s
 		if (boxMode) k_box_setup<<<gridTris, kBlock, 0, stream>>>(in.boxLo, in.boxHi, n, triLo, triHi, bounds);
 		else
 			k_tri_setup<<<gridTris < 2048 ? gridTris : 2048, kBlock, 0, stream>>>(in.vertices, in.indices, n, triLo, triHi,
-			                                                                       bounds);
+			                                                                       bounds, triPos);
 		k_morton<<<gridTris, kBlock, 0, stream>>>(triLo, triHi, n, bounds, codes, keysA, valsA);
 		uint32_t *kin = keysA, *kout = keysB, *vin = valsA, *vout = valsB;
 		for (int shift = 0; shift < 32; shift += 8)
@@ -972,7 +979,7 @@ hipError_t ptBuildBvh4(const PtBuildInput &in, PtBuildOutput &out, hipStream_t s
 			                                         arrive, padScale);
 			k_lbvh_counts<<<gridTris, kBlock, 0, stream>>>(range, (int)n, subCount);
 			// the triangle array is in sorted order: independent of the collapse
-			if (!boxMode) k_write_tris<<<gridTris, kBlock, 0, stream>>>(vin, n, in.vertices, in.indices, tris);
+			if (!boxMode) k_write_tris<<<gridTris, kBlock, 0, stream>>>(vin, n, triPos, tris);
 		}
 		if (err == hipSuccess && ploc)
 		{
@@ -1030,7 +1037,7 @@ hipError_t ptBuildBvh4(const PtBuildInput &in, PtBuildOutput &out, hipStream_t s
 			tin = tout;
 			tout = t;
 		}
-		if (err == hipSuccess && leafPrim) k_write_tris<<<gridTris, kBlock, 0, stream>>>(leafPrim, n, in.vertices, in.indices, tris);
+		if (err == hipSuccess && leafPrim) k_write_tris<<<gridTris, kBlock, 0, stream>>>(leafPrim, n, triPos, tris);
 		TRY(hipGetLastError());
 	}
 	if (err == hipSuccess)
