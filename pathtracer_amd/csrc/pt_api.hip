@@ -352,6 +352,7 @@ extern "C" void pt_destroy(pt_ctx *c)
 extern "C" int pt_set_stream(pt_ctx *c, void *s)
 {
 	if (!c) return fail(nullptr, PT_EINVAL, "null context");
+	PT_HIP(c, hipSetDevice(c->device));
 	PT_HIP(c, hipStreamSynchronize(c->stream));
 	drainEvents(c);
 	c->stream = s ? (hipStream_t)s : c->ownStream;
@@ -361,6 +362,7 @@ extern "C" int pt_set_stream(pt_ctx *c, void *s)
 extern "C" int pt_synchronize(pt_ctx *c)
 {
 	if (!c) return fail(nullptr, PT_EINVAL, "null context");
+	PT_HIP(c, hipSetDevice(c->device));
 	PT_HIP(c, hipStreamSynchronize(c->stream));
 	drainEvents(c);
 	return PT_OK;
@@ -432,7 +434,13 @@ extern "C" int pt_set_texture(pt_ctx *c, const uint8_t *rgba8, uint32_t w, uint3
 	pt_srgb8_to_linear(rgba8, (uint32_t)(4 * n), lin.data());
 	for (size_t i = 0; i < n; ++i) lin[4 * i + 3] = (float)rgba8[4 * i + 3] / 255.0f;  // alpha is not a colour (unused by the shading)
 	PT_HIP(c, hipMalloc(&c->dTexture, sizeof(float4) * n));
-	PT_HIP(c, hipMemcpy(c->dTexture, lin.data(), sizeof(float4) * n, hipMemcpyHostToDevice));
+	hipError_t e = hipMemcpy(c->dTexture, lin.data(), sizeof(float4) * n, hipMemcpyHostToDevice);
+	if (e != hipSuccess)
+	{
+		hipFree(c->dTexture);  // never leave a map without an extent behind: the sampler divides by it
+		c->dTexture = nullptr;
+		return fail(c, PT_EHIP, "pt_set_texture: upload failed: %s", hipGetErrorString(e));
+	}
 	c->texW = w;
 	c->texH = h;
 	return PT_OK;
@@ -480,9 +488,9 @@ int buildTopLevel(pt_ctx *c, int builder)
 		bh[i] = make_float4(wh[0], wh[1], wh[2], 0.0f);
 	}
 	float4 *dLo = nullptr, *dHi = nullptr;
-	PT_HIP(c, hipMalloc(&dLo, sizeof(float4) * n));
-	PT_HIP(c, hipMalloc(&dHi, sizeof(float4) * n));
-	hipError_t e = hipMemcpy(dLo, bl.data(), sizeof(float4) * n, hipMemcpyHostToDevice);
+	hipError_t e = hipMalloc(&dLo, sizeof(float4) * n);
+	if (e == hipSuccess) e = hipMalloc(&dHi, sizeof(float4) * n);
+	if (e == hipSuccess) e = hipMemcpy(dLo, bl.data(), sizeof(float4) * n, hipMemcpyHostToDevice);
 	if (e == hipSuccess) e = hipMemcpy(dHi, bh.data(), sizeof(float4) * n, hipMemcpyHostToDevice);
 	PtBuildInput in = { nullptr, nullptr, n, 1, builder };
 	in.boxLo = dLo;
@@ -984,6 +992,7 @@ extern "C" int pt_write_image_from_device(pt_ctx *c, const void *src)
 {
 	if (!c || !src) return fail(c, PT_EINVAL, "pt_write_image_from_device: null argument");
 	if (!c->image) return fail(c, PT_EINVAL, "pt_write_image_from_device: no image (pt_resize)");
+	PT_HIP(c, hipSetDevice(c->device));
 	PT_HIP(c, hipMemcpyAsync(c->image, src, sizeof(float4) * (size_t)c->W * c->H, hipMemcpyDeviceToDevice, c->stream));
 	return PT_OK;
 }
@@ -1055,6 +1064,7 @@ extern "C" int pt_load_checkpoint(pt_ctx *c, const char *path)
 	c->firstFrame = h.firstFrame;
 	c->frameStride = h.frameStride;
 	c->accumMode = h.accumMode;
+	PT_HIP(c, hipSetDevice(c->device));
 	PT_HIP(c, hipMemcpy(c->image, px.data(), sizeof(float) * px.size(), hipMemcpyHostToDevice));
 	c->frame = h.frame;  // the next pt_render_frame renders frame + 1, as if the run had never stopped
 	return PT_OK;
@@ -1118,6 +1128,7 @@ extern "C" int pt_get_stats(pt_ctx *c, PtStats *out)
 extern "C" int pt_reset_stats(pt_ctx *c)
 {
 	if (!c) return fail(nullptr, PT_EINVAL, "null context");
+	PT_HIP(c, hipSetDevice(c->device));
 	PT_HIP(c, hipStreamSynchronize(c->stream));
 	drainEvents(c);
 	PT_HIP(c, hipMemset(c->dStats, 0, 8 * sizeof(unsigned long long)));
