@@ -33,9 +33,6 @@
 #ifndef PT_PATHS_MAX_ITEMS
 #define PT_PATHS_MAX_ITEMS 8u
 #endif
-#ifndef PT_LDS_NODES
-#define PT_LDS_NODES 16u  // node arrays up to this size are copied into LDS (1 KB per wave)
-#endif
 #ifndef PT_REFILL_LANES
 #define PT_REFILL_LANES 32
 #endif
@@ -64,20 +61,31 @@ __device__ __forceinline__ uint32_t popc64(unsigned long long m) { return (uint3
 // a leaf reference is an instance index: the lane saves its prepared world ray in LDS, transforms the ray with the
 // instance's world-to-object matrix (direction NOT renormalised: t means the same in both spaces), pushes
 // PT_INSTANCE_END and descends into the bottom-level tree; popping the marker restores the world ray.
-template <bool kStats, bool kInst, bool kLdsNodes>
+template <bool kStats, bool kInst, int kNodeMode>
 __global__ void __launch_bounds__(PT_WAVE) PT_PATHS_OCCUPANCY k_paths(PtPathsArgs a)
 {
 	__shared__ uint32_t sStack[kStackLds][PT_WAVE];
 	__shared__ uint32_t sIn[kInFields + (kInst ? 3 : 0)][PT_WAVE];
 	__shared__ uint32_t sDone[kDoneFields + (kInst ? 1 : 0)][kDoneRing];
 	__shared__ uint32_t sSave[kInst ? kSaveFields : 1][PT_WAVE];
-	// tiny scenes (<= PT_LDS_NODES wide nodes, e.g. the Cornell box's 7): a wave-private copy of the node array
-	__shared__ uint4 sNodeMem[kLdsNodes ? PT_LDS_NODES : 1][4];
-	const uint4 (*const sNodes)[4] = kLdsNodes ? sNodeMem : nullptr;
-	if (kLdsNodes)
+	// tiny scenes (e.g. the Cornell box's 7 wide nodes): a wave-private copy of the node array, decoded (PT_NODES_PLANES) or
+	// as it is (PT_NODES_PACKED); see pt_wave_traverse.h
+	constexpr uint32_t kNodeWords = kNodeMode == PT_NODES_PLANES ? PT_LDS_NODES_PLANES * PT_PLANE_REC * 4u
+	                                                             : (kNodeMode == PT_NODES_PACKED ? PT_LDS_NODES_PACKED * 16u : 4u);
+	__shared__ uint4 sNodeMem[kNodeWords / 4u];
+	const uint4 *const sNodes = kNodeMode != PT_NODES_GLOBAL ? sNodeMem : nullptr;
+	if (kNodeMode == PT_NODES_PLANES)
+	{
+		uint32_t *dst = reinterpret_cast<uint32_t *>(sNodeMem);
+		const uint32_t nRec = a.sc.nNodes < PT_LDS_NODES_PLANES ? a.sc.nNodes : PT_LDS_NODES_PLANES;
+		for (uint32_t i = threadIdx.x; i < nRec * (4u * PT_PLANE_REC); i += PT_WAVE)
+			dst[i] = pt_plane_record_word(a.sc.nodes, i / (4u * PT_PLANE_REC), i % (4u * PT_PLANE_REC));
+		__syncthreads();
+	}
+	else if (kNodeMode == PT_NODES_PACKED)
 	{
 		const uint4 *src = reinterpret_cast<const uint4 *>(a.sc.nodes);
-		for (uint32_t i = threadIdx.x; i < a.sc.nNodes * 4u && i < PT_LDS_NODES * 4u; i += PT_WAVE) sNodeMem[i >> 2][i & 3] = src[i];
+		for (uint32_t i = threadIdx.x; i < a.sc.nNodes * 4u && i < PT_LDS_NODES_PACKED * 4u; i += PT_WAVE) sNodeMem[i] = src[i];
 		__syncthreads();
 	}
 
@@ -403,7 +411,7 @@ __global__ void __launch_bounds__(PT_WAVE) PT_PATHS_OCCUPANCY k_paths(PtPathsArg
 		if (doNode && !(cur & PT_LEAF_FLAG))
 		{
 			if (kStats) ++nodeFetches;
-			pt_node_step<kStackLds>(sc, ray, tmin, best, cur, sp, sStack, lane, mySpill, a.spillStride, sNodes);
+			pt_node_step<kStackLds, kNodeMode>(sc, ray, tmin, best, cur, sp, sStack, lane, mySpill, a.spillStride, sNodes);
 		}
 		if (!doNode && (cur & PT_LEAF_FLAG) && cur != PT_TRAVERSAL_DONE)
 		{
@@ -538,21 +546,28 @@ __global__ void __launch_bounds__(256)
 
 void ptLaunchPaths(const PtPathsArgs &args, uint32_t waves, bool stats, hipStream_t s)
 {
-	static const bool ldsOff = getenv("PT_LDS_NODES_OFF") != nullptr;  // A/B knob
+	// A/B knobs: PT_LDS_NODES_OFF = nodes from memory whatever the size, PT_LDS_PLANES_OFF = packed LDS copy only
+	static const bool ldsOff = getenv("PT_LDS_NODES_OFF") != nullptr, planesOff = getenv("PT_LDS_PLANES_OFF") != nullptr;
+	const uint32_t nNodes = args.sc.nNodes;
 	if (args.nInst)
 	{
-		if (stats) k_paths<true, true, false><<<waves, PT_WAVE, 0, s>>>(args);
-		else k_paths<false, true, false><<<waves, PT_WAVE, 0, s>>>(args);
+		if (stats) k_paths<true, true, PT_NODES_GLOBAL><<<waves, PT_WAVE, 0, s>>>(args);
+		else k_paths<false, true, PT_NODES_GLOBAL><<<waves, PT_WAVE, 0, s>>>(args);
 	}
-	else if (args.sc.nNodes && args.sc.nNodes <= PT_LDS_NODES && !ldsOff)
+	else if (nNodes && nNodes <= PT_LDS_NODES_PLANES && !ldsOff && !planesOff)
 	{
-		if (stats) k_paths<true, false, true><<<waves, PT_WAVE, 0, s>>>(args);
-		else k_paths<false, false, true><<<waves, PT_WAVE, 0, s>>>(args);
+		if (stats) k_paths<true, false, PT_NODES_PLANES><<<waves, PT_WAVE, 0, s>>>(args);
+		else k_paths<false, false, PT_NODES_PLANES><<<waves, PT_WAVE, 0, s>>>(args);
+	}
+	else if (nNodes && nNodes <= PT_LDS_NODES_PACKED && !ldsOff)
+	{
+		if (stats) k_paths<true, false, PT_NODES_PACKED><<<waves, PT_WAVE, 0, s>>>(args);
+		else k_paths<false, false, PT_NODES_PACKED><<<waves, PT_WAVE, 0, s>>>(args);
 	}
 	else
 	{
-		if (stats) k_paths<true, false, false><<<waves, PT_WAVE, 0, s>>>(args);
-		else k_paths<false, false, false><<<waves, PT_WAVE, 0, s>>>(args);
+		if (stats) k_paths<true, false, PT_NODES_GLOBAL><<<waves, PT_WAVE, 0, s>>>(args);
+		else k_paths<false, false, PT_NODES_GLOBAL><<<waves, PT_WAVE, 0, s>>>(args);
 	}
 }
 

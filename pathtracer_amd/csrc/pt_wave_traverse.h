@@ -51,59 +51,127 @@ __device__ __forceinline__ PtLaneRay pt_prepare_ray(float3x o, float3x d)
 	return r;
 }
 
-// sNodes != nullptr: the whole node array is resident in LDS (tiny scenes, see k_paths): four ds_read_b128 instead of
-// four divergent-address global loads (each of which costs the frame as much as ~10 VALU instructions).
-template <int kStackLds>
+// Where a node step finds its nodes.
+//   PT_NODES_GLOBAL  the 64-byte records in memory: four divergent-address global loads (each of which costs the frame as
+//                    much as ~10 VALU instructions)
+//   PT_NODES_PACKED  the same records copied into LDS by the caller (node arrays up to PT_LDS_NODES_PACKED): four ds_read_b128
+//   PT_NODES_PLANES  decoded records in LDS (node arrays up to PT_LDS_NODES_PLANES; layout below): the 24 quantised planes are
+//                    stored as the floats (float)q the packed path converts them to on every visit -- same fma, same
+//                    result, 24 v_cvt_f32_ubyte fewer -- near and far planes are picked by address instead of by select,
+//                    and an empty child slot is a box no ray can hit (lo = +inf, hi = -inf) instead of a test on its reference.
+enum
+{
+	PT_NODES_GLOBAL = 0,
+	PT_NODES_PACKED = 1,
+	PT_NODES_PLANES = 2
+};
+#define PT_LDS_NODES_PACKED 16u
+#define PT_LDS_NODES_PLANES 8u
+// decoded record, in 16-byte units: [0] origin.xyz, scaleX  [1] child references  [2] scaleY, scaleZ, -, -
+// [3..5] low planes x, y, z (one float per child)  [6..8] high planes x, y, z
+#define PT_PLANE_REC 9u
+
+// Decodes node `n` of the packed array into word `k` (0 .. 4*PT_PLANE_REC-1) of its decoded record.
+__device__ __forceinline__ uint32_t pt_plane_record_word(const PtNode4 *nodes, uint32_t n, uint32_t k)
+{
+	const uint32_t *w = reinterpret_cast<const uint32_t *>(nodes + n);  // origin[3] scaleX child[4] qlo[3] qhi[3] scaleY scaleZ
+	if (k < 8u) return w[k];
+	if (k < 12u) return k == 8u ? w[14] : (k == 9u ? w[15] : 0u);
+	const uint32_t p = (k - 12u) >> 2, c = (k - 12u) & 3u;  // p: lo x, y, z, hi x, y, z
+	if (w[4u + c] == PT_EMPTY_CHILD) return __float_as_uint(p < 3u ? INFINITY : -INFINITY);
+	return __float_as_uint((float)((w[8u + p] >> (8u * c)) & 0xFFu));
+}
+
+template <int kStackLds, int kNodeMode = PT_NODES_GLOBAL>
 __device__ __forceinline__ void pt_node_step(const PtSceneDev &sc, const PtLaneRay &ray, float tmin, const PtBest &best,
                                              uint32_t &cur, int &sp, uint32_t (*sStack)[PT_WAVE], int lane,
-                                             uint32_t *mySpill, uint32_t spillStride,
-                                             const uint4 (*sNodes)[4] = nullptr)
+                                             uint32_t *mySpill, uint32_t spillStride, const uint4 *sNodes = nullptr)
 {
 	const float ox = ray.ox, oy = ray.oy, oz = ray.oz, ix = ray.ix, iy = ray.iy, iz = ray.iz;
 	const uint32_t kpack = ray.kpack;
-	uint4 n0, n1, n2, n3;
-	if (sNodes)
-	{
-		n0 = sNodes[cur][0];
-		n1 = sNodes[cur][1];
-		n2 = sNodes[cur][2];
-		n3 = sNodes[cur][3];
-	}
-	else
-	{
-		const uint4 *np = reinterpret_cast<const uint4 *>(sc.nodes + cur);
-		n0 = np[0];
-		n1 = np[1];
-		n2 = np[2];
-		n3 = np[3];
-	}
 	// the entry that is popped if no child is hit; read early so its latency hides under the box tests
 	const bool fastStack = sp <= kStackLds - 3;
 	uint32_t top = sStack[sp - 1 < kStackLds ? sp - 1 : 0][lane];
-	float sx = __uint_as_float(n0.w), sy = __uint_as_float(n3.z), sz = __uint_as_float(n3.w);
-	float ax = sx * ix, ay = sy * iy, az = sz * iz;
-	float bx = (__uint_as_float(n0.x) - ox) * ix, by = (__uint_as_float(n0.y) - oy) * iy,
-	      bz = (__uint_as_float(n0.z) - oz) * iz;
 	const bool negx = kpack & 64u, negy = kpack & 128u, negz = kpack & 256u;
-	// n2 = qlo[0..2], qhi[0]; n3 = qhi[1..2], scaleY, scaleZ
-	uint32_t nqx = negx ? n2.w : n2.x, fqx = negx ? n2.x : n2.w;
-	uint32_t nqy = negy ? n3.x : n2.y, fqy = negy ? n2.y : n3.x;
-	uint32_t nqz = negz ? n3.y : n2.z, fqz = negz ? n2.z : n3.y;
-	uint32_t ref[4] = { n1.x, n1.y, n1.z, n1.w };
+	uint32_t ref[4];
 	float tn[4];
-#pragma unroll
-	for (int c = 0; c < 4; ++c)
+	if (kNodeMode == PT_NODES_PLANES)
 	{
-		float tnx = __builtin_fmaf((float)((nqx >> (8 * c)) & 0xFFu), ax, bx);
-		float tny = __builtin_fmaf((float)((nqy >> (8 * c)) & 0xFFu), ay, by);
-		float tnz = __builtin_fmaf((float)((nqz >> (8 * c)) & 0xFFu), az, bz);
-		float tfx = __builtin_fmaf((float)((fqx >> (8 * c)) & 0xFFu), ax, bx);
-		float tfy = __builtin_fmaf((float)((fqy >> (8 * c)) & 0xFFu), ay, by);
-		float tfz = __builtin_fmaf((float)((fqz >> (8 * c)) & 0xFFu), az, bz);
-		float t0 = fmaxf(fmaxf(tnx, tny), fmaxf(tnz, tmin));
-		float t1 = fminf(fminf(tfx, tfy), fminf(tfz, best.t));
-		bool hit = (t0 <= t1 * 1.000001f) && (ref[c] != PT_EMPTY_CHILD);
-		tn[c] = hit ? t0 : INFINITY;
+		const float4 *rec = reinterpret_cast<const float4 *>(sNodes) + cur * PT_PLANE_REC;
+		const float4 h0 = rec[0], h2 = rec[2];
+		const uint4 r4 = *reinterpret_cast<const uint4 *>(rec + 1);
+		const int dx = negx ? 3 : 0, dy = negy ? 3 : 0, dz = negz ? 3 : 0;
+		const float4 qnx = rec[3 + dx], qfx = rec[6 - dx];
+		const float4 qny = rec[4 + dy], qfy = rec[7 - dy];
+		const float4 qnz = rec[5 + dz], qfz = rec[8 - dz];
+		const float ax = h0.w * ix, ay = h2.x * iy, az = h2.y * iz;
+		const float bx = (h0.x - ox) * ix, by = (h0.y - oy) * iy, bz = (h0.z - oz) * iz;
+		ref[0] = r4.x;
+		ref[1] = r4.y;
+		ref[2] = r4.z;
+		ref[3] = r4.w;
+		const float vnx[4] = { qnx.x, qnx.y, qnx.z, qnx.w }, vfx[4] = { qfx.x, qfx.y, qfx.z, qfx.w };
+		const float vny[4] = { qny.x, qny.y, qny.z, qny.w }, vfy[4] = { qfy.x, qfy.y, qfy.z, qfy.w };
+		const float vnz[4] = { qnz.x, qnz.y, qnz.z, qnz.w }, vfz[4] = { qfz.x, qfz.y, qfz.z, qfz.w };
+#pragma unroll
+		for (int c = 0; c < 4; ++c)
+		{
+			float tnx = __builtin_fmaf(vnx[c], ax, bx);
+			float tny = __builtin_fmaf(vny[c], ay, by);
+			float tnz = __builtin_fmaf(vnz[c], az, bz);
+			float tfx = __builtin_fmaf(vfx[c], ax, bx);
+			float tfy = __builtin_fmaf(vfy[c], ay, by);
+			float tfz = __builtin_fmaf(vfz[c], az, bz);
+			float t0 = fmaxf(fmaxf(tnx, tny), fmaxf(tnz, tmin));
+			float t1 = fminf(fminf(tfx, tfy), fminf(tfz, best.t));
+			// an empty slot has t0 = +inf and t1 = -inf whatever the ray (a = scale/d is finite and not zero)
+			tn[c] = (t0 <= t1 * 1.000001f) ? t0 : INFINITY;
+		}
+	}
+	else
+	{
+		uint4 n0, n1, n2, n3;
+		if (kNodeMode == PT_NODES_PACKED)
+		{
+			n0 = sNodes[4u * cur + 0u];
+			n1 = sNodes[4u * cur + 1u];
+			n2 = sNodes[4u * cur + 2u];
+			n3 = sNodes[4u * cur + 3u];
+		}
+		else
+		{
+			const uint4 *np = reinterpret_cast<const uint4 *>(sc.nodes + cur);
+			n0 = np[0];
+			n1 = np[1];
+			n2 = np[2];
+			n3 = np[3];
+		}
+		float sx = __uint_as_float(n0.w), sy = __uint_as_float(n3.z), sz = __uint_as_float(n3.w);
+		float ax = sx * ix, ay = sy * iy, az = sz * iz;
+		float bx = (__uint_as_float(n0.x) - ox) * ix, by = (__uint_as_float(n0.y) - oy) * iy,
+		      bz = (__uint_as_float(n0.z) - oz) * iz;
+		// n2 = qlo[0..2], qhi[0]; n3 = qhi[1..2], scaleY, scaleZ
+		uint32_t nqx = negx ? n2.w : n2.x, fqx = negx ? n2.x : n2.w;
+		uint32_t nqy = negy ? n3.x : n2.y, fqy = negy ? n2.y : n3.x;
+		uint32_t nqz = negz ? n3.y : n2.z, fqz = negz ? n2.z : n3.y;
+		ref[0] = n1.x;
+		ref[1] = n1.y;
+		ref[2] = n1.z;
+		ref[3] = n1.w;
+#pragma unroll
+		for (int c = 0; c < 4; ++c)
+		{
+			float tnx = __builtin_fmaf((float)((nqx >> (8 * c)) & 0xFFu), ax, bx);
+			float tny = __builtin_fmaf((float)((nqy >> (8 * c)) & 0xFFu), ay, by);
+			float tnz = __builtin_fmaf((float)((nqz >> (8 * c)) & 0xFFu), az, bz);
+			float tfx = __builtin_fmaf((float)((fqx >> (8 * c)) & 0xFFu), ax, bx);
+			float tfy = __builtin_fmaf((float)((fqy >> (8 * c)) & 0xFFu), ay, by);
+			float tfz = __builtin_fmaf((float)((fqz >> (8 * c)) & 0xFFu), az, bz);
+			float t0 = fmaxf(fmaxf(tnx, tny), fmaxf(tnz, tmin));
+			float t1 = fminf(fminf(tfx, tfy), fminf(tfz, best.t));
+			bool hit = (t0 <= t1 * 1.000001f) && (ref[c] != PT_EMPTY_CHILD);
+			tn[c] = hit ? t0 : INFINITY;
+		}
 	}
 	// sort the (entry distance, reference) pairs ascending: 5 compare-exchanges; missed children (inf) sink
 #define PT_CE(a, b)                           \

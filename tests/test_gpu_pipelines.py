@@ -175,3 +175,41 @@ def test_many_frames_per_launch_equal_frame_by_frame(rt, pa, cornell, ocornell):
     assert rt.frame == 18
     want11, _ = ocornell.render(view, proj, W, H, frames=11, spp_per_frame=2, max_depth=6, seed=5)
     assert np.array_equal(bits(rt.readImage()), bits(want11))
+
+
+def test_every_node_source_of_the_path_kernel(rt, pa, O):
+    """k_paths reads its nodes from decoded LDS records (<= 8 wide nodes), from a packed LDS copy (<= 16) or from memory
+    (pt_wave_traverse.h): small meshes of growing size land in each of the three, with half-empty nodes among them;
+    image and ray count against the oracle bit for bit, node visits and triangle tests equal to the fused pipeline's."""
+    from pathtracer_amd.api import PT_PROFILE_TRAVERSAL
+    W, H = 96, 64
+    view = pa.look_at((0.0, 1.1, 2.6), (0.0, 0.1, 0.0), (0, 1, 0))
+    proj = pa.perspective(np.radians(45.0), W / H, 0.1, 100.0)
+    proj[5] *= -1
+    seen = set()
+    for nx, nz, leaf in [(1, 1, 0), (2, 2, 0), (3, 3, 0), (4, 3, 0), (4, 4, 0), (5, 5, 0), (6, 5, 1), (7, 7, 0), (9, 8, 0)]:
+        sc = pa.scenes.grid_mesh(nx, nz, size=2.0, amplitude=0.3)
+        osc = O.OracleScene(sc.vertices, sc.indices, sc.materials, sc.mat_indices)
+        rt.uploadScene(sc)
+        rt.buildBlas(None, pa.api.PT_ACCEL_BVH4 | (leaf << 8))
+        nodes = rt.stats().bvh_nodes
+        seen.add("planes" if nodes <= 8 else ("packed" if nodes <= 16 else "global"))
+        rt.resize(W, H)
+        rt.setCamera(view, proj)
+        rt.setParams(spp_per_frame=4, max_depth=6, seed=3)
+        want, rays = osc.render(view, proj, W, H, frames=2, spp_per_frame=4, max_depth=6, seed=3)
+        trav = {}
+        for name in ("persistent", "fused"):  # the fused kernel takes the same steps with nodes from memory
+            rt.setPipeline(PIPELINES[name])
+            for prof in (0, PT_PROFILE_TRAVERSAL):  # the counting kernels are instantiations of their own
+                rt.setProfiling(prof)
+                rt.resetFrame()
+                rt.resetStats()
+                rt.raytrace(2)
+                st = rt.stats()
+                assert st.rays_total == rays, (nx, nz, name)
+                assert np.array_equal(bits(rt.readImage()), bits(want)), (nx, nz, nodes, name, prof)
+            trav[name] = (st.trav_nodes, st.trav_tris, st.trav_hits)
+        assert trav["persistent"] == trav["fused"], (nx, nz, nodes, trav)
+        rt.setProfiling(0)
+    assert seen == {"planes", "packed", "global"}, seen
