@@ -64,6 +64,7 @@ struct pt_ctx
 	int frame = -1;  // m_pcRay.frame
 	bool haveCamera = false;
 	PtCamera cam;
+	PtCamera *dCam = nullptr;  // device copy for the persistent pipeline, rewritten before every launch (stream-ordered)
 
 	PtQueues q = {};
 	size_t queueCap = 0;  // records
@@ -284,6 +285,7 @@ extern "C" pt_ctx *pt_create(int device)
 	c->stream = c->ownStream;
 	ok = ok && hipMalloc(&c->counters, sizeof(PtFrameCounters)) == hipSuccess;
 	ok = ok && hipMalloc(&c->dStats, 8 * sizeof(unsigned long long)) == hipSuccess;
+	ok = ok && hipMalloc(&c->dCam, sizeof(PtCamera)) == hipSuccess;
 	ok = ok && hipMemset(c->dStats, 0, 8 * sizeof(unsigned long long)) == hipSuccess;
 	// persistent grid: blocks of 256 threads per CU (tuning knob PT_BLOCKS_PER_CU, default 4)
 	int blocksPerCU = 4;
@@ -338,6 +340,7 @@ extern "C" void pt_destroy(pt_ctx *c)
 	hipFree(c->image);
 	hipFree(c->counters);
 	hipFree(c->dStats);
+	hipFree(c->dCam);
 	hipFree(c->cfg.spill);
 	hipFree(c->cfg.waveRays);
 	hipFree(c->dLcgSkip);
@@ -819,7 +822,8 @@ int renderPersistent(pt_ctx *c, int n)
 		}
 		PtPathsArgs pa;
 		pa.sc = sc;
-		pa.cam = c->cam;
+		ptLaunchStoreCamera(c->cam, c->dCam, s);
+		pa.cam = c->dCam;
 		pa.W = c->W;
 		pa.H = c->H;
 		pa.tile = tile;

@@ -103,15 +103,15 @@ struct PtCamera
 };
 
 // raytrace.rgen:40-46 with inverse(view)/inverse(proj) hoisted to the host.  Matrix * vector in
-// glm's association: (m0*x + m1*y) + (m2*z + m3*w).
-__device__ __forceinline__ void pt_camera_ray(const PtCamera &cam, uint32_t W, uint32_t H, uint32_t px, uint32_t py,
-                                              float jx, float jy, float3x &o, float3x &d)
+// glm's association: (m0*x + m1*y) + (m2*z + m3*w).  V, P: the two inverse matrices (column-major), through any pointer type.
+template <typename FP>
+__device__ __forceinline__ void pt_camera_ray_from(FP V, FP P, uint32_t W, uint32_t H, uint32_t px, uint32_t py, float jx,
+                                                   float jy, float3x &o, float3x &d)
 {
 	float uvx = ((float)px + jx) / (float)W;
 	float uvy = ((float)py + jy) / (float)H;
 	float dx = uvx * 2.0f - 1.0f;
 	float dy = uvy * 2.0f - 1.0f;
-	const float *V = cam.invView, *P = cam.invProj;
 	o.x = (V[0] * 0.0f + V[4] * 0.0f) + (V[8] * 0.0f + V[12] * 1.0f);
 	o.y = (V[1] * 0.0f + V[5] * 0.0f) + (V[9] * 0.0f + V[13] * 1.0f);
 	o.z = (V[2] * 0.0f + V[6] * 0.0f) + (V[10] * 0.0f + V[14] * 1.0f);
@@ -124,6 +124,16 @@ __device__ __forceinline__ void pt_camera_ray(const PtCamera &cam, uint32_t W, u
 	d.y = (V[1] * n.x + V[5] * n.y) + (V[9] * n.z + V[13] * 0.0f);
 	d.z = (V[2] * n.x + V[6] * n.y) + (V[10] * n.z + V[14] * 0.0f);
 }
+
+__device__ __forceinline__ void pt_camera_ray(const PtCamera &cam, uint32_t W, uint32_t H, uint32_t px, uint32_t py,
+                                              float jx, float jy, float3x &o, float3x &d)
+{
+	pt_camera_ray_from<const float *>(cam.invView, cam.invProj, W, H, px, py, jx, jy, o, d);
+}
+
+// Uniform read-only data behind a pointer in the constant address space: read with scalar loads where it is used
+// instead of living in SGPRs for the whole kernel.
+typedef const float __attribute__((address_space(4))) pt_const_float;
 
 // ------------------------------------------------------- watertight ray/triangle test ----
 // Woop, Benthin, Wald, "Watertight Ray/Triangle Intersection" (JCGT 2013), without backface

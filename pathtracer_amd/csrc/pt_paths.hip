@@ -313,7 +313,12 @@ __global__ void __launch_bounds__(PT_WAVE) PT_PATHS_OCCUPANCY k_paths(PtPathsArg
 							const bool centre = f == a.centreFrame;  // rgen:38: frame 0 samples the pixel centre
 							float jx = centre ? 0.5f : r1, jy = centre ? 0.5f : r2;
 							float3x o, d;
-							pt_camera_ray(a.cam, a.W, a.H, genPx, genPy, jx, jy, o, d);
+							// the matrices are fetched here, by scalar loads; the empty asm keeps the loads from being hoisted
+							// out of the loop (where they would occupy 32 SGPRs for good)
+							unsigned long long camAddr = reinterpret_cast<unsigned long long>(a.cam);
+							asm volatile("" : "+s"(camAddr));
+							pt_const_float *cm = reinterpret_cast<pt_const_float *>(camAddr);
+							pt_camera_ray_from<pt_const_float *>(cm, cm + 16, a.W, a.H, genPx, genPy, jx, jy, o, d);
 							uint32_t pq = item * PT_WAVE + lane;
 							// payload.seed = seed: the bounce stream starts from the state after the two jitter
 							// draws, while the raygen-local seed continues from the same state for the next sample
@@ -543,6 +548,17 @@ __global__ void __launch_bounds__(256)
 	image[p] = out;
 }
 }  // namespace
+
+namespace
+{
+__global__ void k_store_camera(PtCamera cam, PtCamera *dst)
+{
+	const float *src = cam.invView;  // invView and invProj are contiguous: 32 floats
+	if (threadIdx.x < 32) dst->invView[threadIdx.x] = src[threadIdx.x];
+}
+}  // namespace
+
+void ptLaunchStoreCamera(const PtCamera &cam, PtCamera *dst, hipStream_t s) { k_store_camera<<<1, 64, 0, s>>>(cam, dst); }
 
 void ptLaunchPaths(const PtPathsArgs &args, uint32_t waves, bool stats, hipStream_t s)
 {

@@ -67,7 +67,9 @@ void ptLaunchBounce(const PtSceneDev &sc, const PtQueues &q, int in, PtFrameCoun
 struct PtPathsArgs
 {
 	PtSceneDev sc;
-	PtCamera cam;
+	// in device memory (ptLaunchStoreCamera), not in the argument block: 32 SGPRs that only the camera-ray generation
+	// needs would otherwise be held -- and spilled around -- through the whole kernel
+	const PtCamera *cam;
 	uint32_t W, H, spp;
 	// One launch renders nFrames consecutive frames of the schedule (the drain at the end of a launch -- waves
 	// finishing their last paths at low lane utilisation, ~0.3 ms -- is paid once per launch, not per frame):
@@ -90,6 +92,7 @@ struct PtPathsArgs
 	uint32_t nInst, tlasRoot;
 };
 void ptLaunchPaths(const PtPathsArgs &args, uint32_t waves, bool stats, hipStream_t s);
+void ptLaunchStoreCamera(const PtCamera &cam, PtCamera *dst, hipStream_t s);
 void ptLaunchAccumulateItems(const float4 *rad, PtTile tile, uint32_t W, uint32_t spp, float4 *image, uint32_t lframe0,
                              uint32_t nFrames, int mode, hipStream_t s);
 void ptLaunchAccumulate(const PtQueues &q, PtTile tile, uint32_t W, uint32_t spp, float4 *image, uint32_t lframe, int mode,
