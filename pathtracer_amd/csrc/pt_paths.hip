@@ -55,6 +55,30 @@ constexpr int kDoneRing = 128;
 constexpr uint32_t kRefillLanes = PT_REFILL_LANES;
 constexpr uint32_t kNoPath = 0xFFFFFFFFu;
 
+// A kernel argument that only a cold part of k_paths needs (camera-ray generation, the gather fallback of the shading,
+// the epilogue), read from the kernarg segment WHERE it is used: the block of arguments is ~60 SGPRs, and what the
+// compiler loads at entry it keeps -- or spills to VGPR lanes and restores with v_readlane_b32, a VALU instruction each --
+// for the whole kernel.  The empty asm makes the address opaque, so the scalar load cannot be hoisted back to the entry.
+// (k_paths has ONE by-value argument, so PtPathsArgs starts at offset 0 of the kernarg segment.)
+template <typename T>
+__device__ __forceinline__ T pt_cold_arg(uint32_t offset)
+{
+	static_assert(sizeof(T) % 4 == 0, "whole dwords");
+	unsigned long long p = reinterpret_cast<unsigned long long>(__builtin_amdgcn_kernarg_segment_ptr());
+	asm volatile("" : "+s"(p));
+	const uint32_t __attribute__((address_space(4))) *w =
+	    reinterpret_cast<const uint32_t __attribute__((address_space(4))) *>(p + offset);
+	union
+	{
+		T value;
+		uint32_t word[sizeof(T) / 4];
+	} r;
+#pragma unroll
+	for (uint32_t i = 0; i < sizeof(T) / 4; ++i) r.word[i] = w[i];
+	return r.value;
+}
+#define PT_COLD(field) pt_cold_arg<decltype(PtPathsArgs::field)>((uint32_t)offsetof(PtPathsArgs, field))
+
 __device__ __forceinline__ uint32_t popc64(unsigned long long m) { return (uint32_t)__popcll(m); }
 
 // kInst: two-level scene (pt_set_instances).  A lane starts in the top-level tree (inst == PT_NO_INSTANCE), where
@@ -131,6 +155,20 @@ __global__ void __launch_bounds__(PT_WAVE) PT_PATHS_OCCUPANCY k_paths(PtPathsArg
 		bool alive = false;
 		float3x no = { 0, 0, 0 }, nd = { 0, 0, 0 };
 		uint32_t pq = 0, depth = 0;
+		const int maxDepth = PT_COLD(maxDepth);
+		// what the shading reads: the per-primitive records, or (no records / a diffuse map) the reference's gather
+		PtSceneDev fsc = {};
+		fsc.shade = sc.shade;
+		fsc.texture = PT_COLD(sc.texture);
+		if (!fsc.shade || fsc.texture)  // wave-uniform
+		{
+			fsc.vertices = PT_COLD(sc.vertices);
+			fsc.indices = PT_COLD(sc.indices);
+			fsc.materials = PT_COLD(sc.materials);
+			fsc.matIndices = PT_COLD(sc.matIndices);
+			fsc.texW = PT_COLD(sc.texW);
+			fsc.texH = PT_COLD(sc.texH);
+		}
 		if ((uint32_t)lane < count)
 		{
 			uint32_t e = (doneHead + lane) & (kDoneRing - 1);
@@ -144,7 +182,7 @@ __global__ void __launch_bounds__(PT_WAVE) PT_PATHS_OCCUPANCY k_paths(PtPathsArg
 				float4 T = a.state[pq];  // throughput, rng state
 				uint32_t seed = __float_as_uint(T.w);
 				float3x kd, ke;
-				pt_shade_hit(sc, prim, u, v, seed, no, nd, kd, ke,
+				pt_shade_hit(fsc, prim, u, v, seed, no, nd, kd, ke,
 				             kInst ? a.instances + 24 * (size_t)sDone[kDoneFields][e] : nullptr);
 				float ex = ke.x, ey = ke.y, ez = ke.z;
 				if (ex != 0.0f || ey != 0.0f || ez != 0.0f)
@@ -156,7 +194,7 @@ __global__ void __launch_bounds__(PT_WAVE) PT_PATHS_OCCUPANCY k_paths(PtPathsArg
 					L.z += ez * T.z;
 					a.rad[pq] = L;
 				}
-				alive = (int)(depth + 1) < a.maxDepth && !((ex + ey) + ez > 0.0f);  // rgen:61 loop bound, rchit:56-58
+				alive = (int)(depth + 1) < maxDepth && !((ex + ey) + ez > 0.0f);  // rgen:61 loop bound, rchit:56-58
 				if (alive)  // curAttenuation *= hitValue (rgen:79)
 					a.state[pq] = make_float4(T.x * kd.x, T.y * kd.y, T.z * kd.z, __uint_as_float(seed));
 				if (kStats) ++nHits;
@@ -273,7 +311,7 @@ __global__ void __launch_bounds__(PT_WAVE) PT_PATHS_OCCUPANCY k_paths(PtPathsArg
 								k = share >= PT_PATHS_MAX_ITEMS ? PT_PATHS_MAX_ITEMS
 								                                : (share <= PT_PATHS_MIN_ITEMS ? PT_PATHS_MIN_ITEMS : share);
 								c = 0;
-								if (lane == 0) c = atomicAdd(a.itemHead, k);
+								if (lane == 0) c = atomicAdd(PT_COLD(itemHead), k);
 								c = __builtin_amdgcn_readfirstlane(c) + headBias;
 							}
 							if (c >= totalItems)
@@ -288,19 +326,21 @@ __global__ void __launch_bounds__(PT_WAVE) PT_PATHS_OCCUPANCY k_paths(PtPathsArg
 						}
 						const uint32_t item = itemCur++;
 						const uint32_t f = item / itemsPerFrame, local = item - f * itemsPerFrame;  // frame of the launch
-						const uint32_t g = local / a.spp, i = local - g * a.spp;
+						const uint32_t spp = PT_COLD(spp);
+						const uint32_t g = local / spp, i = local - g * spp;
 						if (needSeed || i == 0)
 						{
 							needSeed = false;
 							uint32_t p = g * PT_WAVE + lane;
 							genValid = p < WH;
-							const uint32_t ty = p / a.tile.w;
-							genPy = a.tile.y0 + ty;
-							genPx = a.tile.x0 + (p - ty * a.tile.w);
-							genSeed = pt_tea(genPy * a.W + genPx, a.seedWord + f * a.frameStride);  // rgen:28, val1 = seed + global frame
+							const PtTile tile = PT_COLD(tile);
+							const uint32_t ty = p / tile.w;
+							genPy = tile.y0 + ty;
+							genPx = tile.x0 + (p - ty * tile.w);
+							genSeed = pt_tea(genPy * PT_COLD(W) + genPx, PT_COLD(seedWord) + f * PT_COLD(frameStride));  // rgen:28, val1 = seed + global frame
 							if (i)
 							{
-								uint2 ac = a.lcgSkip[i];  // state after 2*i lcg steps = A * s + C
+								uint2 ac = PT_COLD(lcgSkip)[i];  // state after 2*i lcg steps = A * s + C
 								genSeed = ac.x * genSeed + ac.y;
 							}
 						}
@@ -310,15 +350,15 @@ __global__ void __launch_bounds__(PT_WAVE) PT_PATHS_OCCUPANCY k_paths(PtPathsArg
 						{
 							float r1 = pt_rnd(genSeed);
 							float r2 = pt_rnd(genSeed);
-							const bool centre = f == a.centreFrame;  // rgen:38: frame 0 samples the pixel centre
+							const bool centre = f == PT_COLD(centreFrame);  // rgen:38: frame 0 samples the pixel centre
 							float jx = centre ? 0.5f : r1, jy = centre ? 0.5f : r2;
 							float3x o, d;
 							// the matrices are fetched here, by scalar loads; the empty asm keeps the loads from being hoisted
 							// out of the loop (where they would occupy 32 SGPRs for good)
-							unsigned long long camAddr = reinterpret_cast<unsigned long long>(a.cam);
+							unsigned long long camAddr = reinterpret_cast<unsigned long long>(PT_COLD(cam));
 							asm volatile("" : "+s"(camAddr));
 							pt_const_float *cm = reinterpret_cast<pt_const_float *>(camAddr);
-							pt_camera_ray_from<pt_const_float *>(cm, cm + 16, a.W, a.H, genPx, genPy, jx, jy, o, d);
+							pt_camera_ray_from<pt_const_float *>(cm, cm + 16, PT_COLD(W), PT_COLD(H), genPx, genPy, jx, jy, o, d);
 							uint32_t pq = item * PT_WAVE + lane;
 							// payload.seed = seed: the bounce stream starts from the state after the two jitter
 							// draws, while the raygen-local seed continues from the same state for the next sample
@@ -485,7 +525,7 @@ __global__ void __launch_bounds__(PT_WAVE) PT_PATHS_OCCUPANCY k_paths(PtPathsArg
 		}
 	}
 
-	if (lane == 0 && raysFetched) a.waveRays[blockIdx.x] += raysFetched;  // one wave per slot: no atomic needed
+	if (lane == 0 && raysFetched) PT_COLD(waveRays)[blockIdx.x] += raysFetched;  // one wave per slot: no atomic needed
 	if (kStats)
 	{
 		unsigned long long x = nodeFetches, y = triTests, z = nHits, w = leafVisits;
