@@ -81,6 +81,15 @@ __device__ __forceinline__ T pt_cold_arg(uint32_t offset)
 
 __device__ __forceinline__ uint32_t popc64(unsigned long long m) { return (uint32_t)__popcll(m); }
 
+// Population count of a wave-uniform mask (a ballot) as a 32-bit scalar.  Without the empty asm the optimiser compares two
+// such counts as the 64-bit values __popcll returns, and a 64-bit ordered compare only exists on the VALU (v_cmp_ge_u64).
+__device__ __forceinline__ uint32_t popcWave(unsigned long long m)
+{
+	uint32_t n = (uint32_t)__popcll(m);
+	asm("" : "+s"(n));
+	return n;
+}
+
 // kInst: two-level scene (pt_set_instances).  A lane starts in the top-level tree (inst == PT_NO_INSTANCE), where
 // a leaf reference is an instance index: the lane saves its prepared world ray in LDS, transforms the ray with the
 // instance's world-to-object matrix (direction NOT renormalised: t means the same in both spaces), pushes
@@ -208,7 +217,7 @@ __global__ void __launch_bounds__(PT_WAVE) PT_PATHS_OCCUPANCY k_paths(PtPathsArg
 			ringO[slot] = make_float4(no.x, no.y, no.z, __uint_as_float(depth + 1));
 			ringD[slot] = make_float4(nd.x, nd.y, nd.z, __uint_as_float(pq));
 		}
-		ringCount += popc64(am);
+		ringCount += popcWave(am);
 	};
 
 	// Writes lane's prepared ray into the staging area.
@@ -237,7 +246,7 @@ __global__ void __launch_bounds__(PT_WAVE) PT_PATHS_OCCUPANCY k_paths(PtPathsArg
 	{
 		// Retire + refill only when enough lanes wait for it (or nothing else is left to do): the section
 		// costs about half a node step, so it is not run for every single finished lane.
-		const uint32_t nIdle = popc64(__ballot(cur == PT_TRAVERSAL_DONE));
+		const uint32_t nIdle = popcWave(__ballot(cur == PT_TRAVERSAL_DONE));
 		if (nIdle >= kRefillLanes)
 		{
 			// ------------------------------------------------------------------ C: retire finished lanes ----
@@ -257,7 +266,7 @@ __global__ void __launch_bounds__(PT_WAVE) PT_PATHS_OCCUPANCY k_paths(PtPathsArg
 					if (kInst) sDone[kDoneFields][e] = bestInst;
 					q = kNoPath;
 				}
-				doneTail += popc64(fm);
+				doneTail += popcWave(fm);
 				if (doneTail - doneHead >= PT_WAVE)
 				{
 					__syncthreads();
@@ -344,7 +353,7 @@ __global__ void __launch_bounds__(PT_WAVE) PT_PATHS_OCCUPANCY k_paths(PtPathsArg
 								genSeed = ac.x * genSeed + ac.y;
 							}
 						}
-						n = popc64(__ballot(genValid));  // valid lanes are 0 .. n-1 (only the last group is partial)
+						n = popcWave(__ballot(genValid));  // valid lanes are 0 .. n-1 (only the last group is partial)
 						__syncthreads();
 						if (genValid)
 						{
@@ -371,7 +380,7 @@ __global__ void __launch_bounds__(PT_WAVE) PT_PATHS_OCCUPANCY k_paths(PtPathsArg
 					else
 					{
 						// nothing to stage: in the drain, shade a partial batch early so its survivors keep lanes busy
-						if (doneTail != doneHead && popc64(idle) >= 32u)
+						if (doneTail != doneHead && popcWave(idle) >= 32u)
 						{
 							__syncthreads();
 							flush(doneTail - doneHead);
@@ -385,7 +394,7 @@ __global__ void __launch_bounds__(PT_WAVE) PT_PATHS_OCCUPANCY k_paths(PtPathsArg
 					inPos = 0;
 					raysFetched += n;
 				}
-				uint32_t avail = inCount - inPos, want = popc64(idle);
+				uint32_t avail = inCount - inPos, want = popcWave(idle);
 				uint32_t n = want < avail ? want : avail;
 				uint32_t rank = popc64(idle & lanesBelow);
 				bool take = (idle & laneBit) && rank < n;
@@ -446,7 +455,7 @@ __global__ void __launch_bounds__(PT_WAVE) PT_PATHS_OCCUPANCY k_paths(PtPathsArg
 		// One step for the LARGER of the two groups (majority-phase stepping, see pt_bounce.hip).
 		const unsigned long long nodeLanes = __ballot(!(cur & PT_LEAF_FLAG));
 		const unsigned long long leafLanes = __ballot((cur & PT_LEAF_FLAG) && cur != PT_TRAVERSAL_DONE);
-		const bool doNode = popc64(nodeLanes) >= popc64(leafLanes);
+		const bool doNode = popcWave(nodeLanes) >= popcWave(leafLanes);
 		const PtLaneRay ray = { ox, oy, oz, ix, iy, iz, Sx, Sy, Sz, kpack };
 		if (kStats)
 		{
