@@ -24,6 +24,8 @@
 // (A^2i, C_2i) from a table the host computes.
 #include <stdlib.h>
 
+#include <type_traits>
+
 #include "pt_trace.h"
 #include "pt_wave_traverse.h"
 
@@ -75,7 +77,13 @@ __device__ __forceinline__ T pt_cold_arg(uint32_t offset)
 	} r;
 #pragma unroll
 	for (uint32_t i = 0; i < sizeof(T) / 4; ++i) r.word[i] = w[i];
-	return r.value;
+	if constexpr (std::is_pointer<T>::value)
+	{
+		// a pointer argument points to device memory: say so, or its loads become flat_load instead of global_load
+		typedef typename std::remove_pointer<T>::type __attribute__((address_space(1))) *GlobalPtr;
+		return (T) reinterpret_cast<GlobalPtr>(reinterpret_cast<unsigned long long>(r.value));
+	}
+	else return r.value;
 }
 #define PT_COLD(field) pt_cold_arg<decltype(PtPathsArgs::field)>((uint32_t)offsetof(PtPathsArgs, field))
 
