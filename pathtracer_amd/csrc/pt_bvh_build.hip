@@ -554,40 +554,56 @@ __global__ void __launch_bounds__(kBlock)
 		}
 		else
 		{
-			float area[4] = { 0, 0, 0, 0 };
+			// slot[], cnt[], area[] are only ever indexed by unrolled loop counters (a run-time index would put them in
+			// scratch memory): "write entry s" is a select over the four entries
+			float area[4] = { -1.0f, -1.0f, -1.0f, -1.0f };
 			auto put = [&](int s, int nd) {
-				slot[s] = nd;
-				cnt[s] = subCount[nd];
-				area[s] = (int)cnt[s] <= leafMax ? -1.0f : halfArea(boxes + 8 * (size_t)nd);  // leaf children are never opened
+				const uint32_t c = subCount[nd];
+				const float ar = (int)c <= leafMax ? -1.0f : halfArea(boxes + 8 * (size_t)nd);  // leaf children are never opened
+#pragma unroll
+				for (int k = 0; k < 4; ++k)
+					if (k == s)
+					{
+						slot[k] = nd;
+						cnt[k] = c;
+						area[k] = ar;
+					}
 			};
 			int2 ch = children[task.bvh2];
 			put(0, ch.x);
 			put(1, ch.y);
 			nSlots = 2;
-			while (nSlots < 4)
+#pragma unroll
+			for (int round = 0; round < 2; ++round)
 			{
-				int best = -1;
+				int best = -1, bestNode = 0;
 				float bestArea = -1.0f;
-				for (int s = 0; s < nSlots; ++s)
-					if (area[s] > bestArea)
+#pragma unroll
+				for (int k = 0; k < 4; ++k)
+					if (k < nSlots && area[k] > bestArea)
 					{
-						bestArea = area[s];
-						best = s;
+						bestArea = area[k];
+						best = k;
+						bestNode = slot[k];
 					}
-				if (best < 0) break;
-				int2 ch2 = children[slot[best]];
-				put(best, ch2.x);
-				put(nSlots++, ch2.y);
+				if (best >= 0)  // otherwise every child is a leaf: nothing to open, in this round or the next
+				{
+					int2 ch2 = children[bestNode];
+					put(best, ch2.x);
+					put(nSlots++, ch2.y);
+				}
 			}
 		}
 	}
 	// queue positions / node ids of the inner children and (PLOC) triangle slots of the leaf children
 	uint32_t nInner = 0, nLeafTris = 0;
-	for (int s = 0; s < nSlots; ++s)
-	{
-		if ((int)cnt[s] <= leafMax) nLeafTris += cnt[s];
-		else ++nInner;
-	}
+#pragma unroll
+	for (int s = 0; s < 4; ++s)
+		if (s < nSlots)
+		{
+			if ((int)cnt[s] <= leafMax) nLeafTris += cnt[s];
+			else ++nInner;
+		}
 	unsigned long long total;
 	const unsigned long long ex = blockExclusiveScan((unsigned long long)nInner | ((unsigned long long)nLeafTris << 32), sWave, total);
 	if (threadIdx.x == 0)
@@ -602,18 +618,20 @@ __global__ void __launch_bounds__(kBlock)
 	// node frame: origin = min corner, power-of-two scale per axis covering the extent in 255 steps
 	float4 blo[4], bhi[4];
 	float org[3] = { INFINITY, INFINITY, INFINITY }, top[3] = { -INFINITY, -INFINITY, -INFINITY };
-	for (int s = 0; s < nSlots; ++s)
-	{
-		const float4 *b = reinterpret_cast<const float4 *>(boxes + 8 * (size_t)slot[s]);
-		blo[s] = b[0];
-		bhi[s] = b[1];
-		org[0] = fminf(org[0], blo[s].x);
-		org[1] = fminf(org[1], blo[s].y);
-		org[2] = fminf(org[2], blo[s].z);
-		top[0] = fmaxf(top[0], bhi[s].x);
-		top[1] = fmaxf(top[1], bhi[s].y);
-		top[2] = fmaxf(top[2], bhi[s].z);
-	}
+#pragma unroll
+	for (int s = 0; s < 4; ++s)
+		if (s < nSlots)
+		{
+			const float4 *b = reinterpret_cast<const float4 *>(boxes + 8 * (size_t)slot[s]);
+			blo[s] = b[0];
+			bhi[s] = b[1];
+			org[0] = fminf(org[0], blo[s].x);
+			org[1] = fminf(org[1], blo[s].y);
+			org[2] = fminf(org[2], blo[s].z);
+			top[0] = fmaxf(top[0], bhi[s].x);
+			top[1] = fmaxf(top[1], bhi[s].y);
+			top[2] = fmaxf(top[2], bhi[s].z);
+		}
 	float scale[3];
 #pragma unroll
 	for (int a = 0; a < 3; ++a)
@@ -644,15 +662,19 @@ __global__ void __launch_bounds__(kBlock)
 	node.scaleX = scale[0];
 	node.scaleY = scale[1];
 	node.scaleZ = scale[2];
+#pragma unroll
 	for (int a = 0; a < 3; ++a)
 	{
 		node.qlo[a] = 0xFFFFFFFFu;  // empty slots: lo = 255, hi = 0
 		node.qhi[a] = 0u;
 	}
+#pragma unroll
 	for (int c = 0; c < 4; ++c) node.child[c] = PT_EMPTY_CHILD;
 
-	for (int s = 0; s < nSlots; ++s)
+#pragma unroll
+	for (int s = 0; s < 4; ++s)
 	{
+		if (s >= nSlots) continue;
 		const float lo3[3] = { blo[s].x, blo[s].y, blo[s].z }, hi3[3] = { bhi[s].x, bhi[s].y, bhi[s].z };
 #pragma unroll
 		for (int a = 0; a < 3; ++a)
