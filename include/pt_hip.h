@@ -83,6 +83,9 @@ typedef struct PtStats
 	 * triangles, codes, order) after compaction and as the builder had to size it before knowing the node count */
 	uint64_t accel_bytes;
 	uint64_t accel_bytes_uncompacted;
+	/* Two-triangle leaves stored as quads for the persistent pipeline (0: the scene is not made of quad faces, or
+	 * PT_NO_QUADS is set); they cost 192 bytes each plus one more copy of the node array, not counted above */
+	uint64_t quad_leaves;
 } PtStats;
 
 typedef struct pt_ctx pt_ctx;

@@ -33,7 +33,7 @@ class PtStats(C.Structure):
                 ("bvh_depth", C.c_uint32), ("bvh_tris", C.c_uint32), ("reserved", C.c_uint32),
                 ("build_ms", C.c_double), ("trav_nodes", C.c_uint64), ("trav_tris", C.c_uint64),
                 ("trav_hits", C.c_uint64), ("trav_leaf_visits", C.c_uint64), ("trav_node_steps", C.c_uint64),
-                ("trav_leaf_steps", C.c_uint64), ("accel_bytes", C.c_uint64), ("accel_bytes_uncompacted", C.c_uint64)]
+                ("trav_leaf_steps", C.c_uint64), ("accel_bytes", C.c_uint64), ("accel_bytes_uncompacted", C.c_uint64), ("quad_leaves", C.c_uint64)]
 
 
 # every symbol include/pt_hip.h declares: name -> (restype, argtypes)

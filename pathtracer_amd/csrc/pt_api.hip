@@ -45,6 +45,7 @@ struct pt_ctx
 	float4 *dTexture = nullptr;  // optional diffuse map (pt_set_texture), linear RGBA
 	uint32_t texW = 0, texH = 0;
 	PtBuildOutput accel;
+	PtQuadOutput quadAccel;  // quad leaves + the node array that refers to them (persistent pipeline only)
 	double buildMs = 0.0;
 	uint64_t accelBytes = 0, accelBytesUncompacted = 0;  // acceleration-structure memory after / before compaction
 	// two-level scenes (pt_set_instances): 24 floats per instance (object-to-world 3x4, world-to-object 3x4)
@@ -134,6 +135,9 @@ void freeAccel(pt_ctx *c)
 	hipFree(c->accel.codes);
 	hipFree(c->accel.order);
 	c->accel = PtBuildOutput();
+	hipFree(c->quadAccel.nodes);
+	hipFree(c->quadAccel.quads);
+	c->quadAccel = PtQuadOutput();
 	c->haveAccel = false;
 }
 
@@ -190,6 +194,8 @@ PtSceneDev sceneDev(const pt_ctx *c)
 	s.texture = c->dTexture;
 	s.texW = c->texW;
 	s.texH = c->texH;
+	s.quads = nullptr;  // only the persistent pipeline traverses the quad version of the tree (renderPersistent)
+	s.nQuads = 0;
 	return s;
 }
 
@@ -581,6 +587,16 @@ extern "C" int pt_build_accel(pt_ctx *c, int flags)
 			c->accelBytes = fixed + (uint64_t)c->accel.nNodes * sizeof(PtNode4);
 		}
 	}
+	if (!c->nInst && !c->brute && c->accel.nNodes && (leafMax == 0 ? PT_LEAF_DEFAULT : leafMax) <= 7 && !getenv("PT_NO_QUADS"))
+	{
+		// scenes made of quad faces: two-triangle fan leaves become quad leaves for k_paths (pt_build.h)
+		hipError_t qe = ptBuildQuadLeaves(c->accel.nodes, c->accel.nNodes, c->accel.tris, c->accel.nTris, 0.9f, c->quadAccel, c->stream);
+		if (qe != hipSuccess)
+		{
+			freeAccel(c);
+			return fail(c, PT_EHIP, "pt_build_accel: quad leaves failed: %s", hipGetErrorString(qe));
+		}
+	}
 	if (c->nInst && !c->brute && c->accel.nNodes)
 	{
 		int rc = buildTopLevel(c, in.builder);
@@ -798,6 +814,12 @@ int renderPersistent(pt_ctx *c, int n)
 	if (rc) return rc;
 	hipStream_t s = c->stream;
 	PtSceneDev sc = sceneDev(c);
+	if (c->quadAccel.nQuads)
+	{
+		sc.nodes = c->quadAccel.nodes;
+		sc.quads = c->quadAccel.quads;
+		sc.nQuads = c->quadAccel.nQuads;
+	}
 	unsigned long long *trav = (c->profiling & PT_PROFILE_TRAVERSAL) ? c->dStats + 2 : nullptr;
 	while (n > 0)
 	{
@@ -1120,6 +1142,7 @@ extern "C" int pt_get_stats(pt_ctx *c, PtStats *out)
 	out->build_ms = c->buildMs;
 	out->accel_bytes = c->accelBytes;
 	out->accel_bytes_uncompacted = c->accelBytesUncompacted;
+	out->quad_leaves = c->quadAccel.nQuads;
 	out->trav_nodes = h[2];
 	out->trav_tris = h[3];
 	out->trav_hits = h[4];

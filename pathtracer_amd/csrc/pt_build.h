@@ -33,3 +33,16 @@ struct PtBuildOutput
 // Builds the quantised BVH4 on `stream`; synchronises the stream (one-time build, as the reference
 // blocks in vkQueueWaitIdle).  On success the caller owns the four device allocations in `out`.
 hipError_t ptBuildBvh4(const PtBuildInput &in, PtBuildOutput &out, hipStream_t stream);
+
+// Quad leaves for k_paths (PtQuad64): a copy of the node array in which every two-triangle leaf whose triangles are the
+// fan (a, b, c), (a, c, d) -- what an OBJ quad face becomes -- is replaced by a reference PT_LEAF_FLAG | PT_LEAF_QUAD << 28 |
+// quad index.  Only done when at least minShare of the triangles end up in quads (a wave pays for both leaf formats when
+// its lanes mix them); otherwise nQuads == 0 and nothing is allocated.  The caller owns the two allocations.
+struct PtQuadOutput
+{
+	PtNode4 *nodes = nullptr;    // device, nNodes
+	PtQuad64 *quads = nullptr;   // device, 3 planes x nQuads
+	uint32_t nQuads = 0;
+};
+hipError_t ptBuildQuadLeaves(const PtNode4 *nodes, uint32_t nNodes, const PtTri48 *tris, uint32_t nTris, float minShare,
+                             PtQuadOutput &out, hipStream_t stream);

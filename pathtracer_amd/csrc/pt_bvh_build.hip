@@ -1089,3 +1089,116 @@ hipError_t ptBuildBvh4(const PtBuildInput &in, PtBuildOutput &out, hipStream_t s
 	out.depth = depth;
 	return hipSuccess;
 }
+
+// ------------------------------------------------------------------------- quad leaves ----
+namespace
+{
+// 0: not a fan pair; 1: A = first triangle, B = second; 2: A = second, B = first.  x, y: the two records of the leaf in
+// plane 2 (coordinates in x, y, z order).  Vertices are compared bit for bit (the shared edge function must be exact).
+__device__ __forceinline__ int quadPattern(const PtTri48 &x, const PtTri48 &y)
+{
+	auto same = [](const float *p, const float *q) {
+		return __float_as_uint(p[0]) == __float_as_uint(q[0]) && __float_as_uint(p[1]) == __float_as_uint(q[1]) &&
+		       __float_as_uint(p[2]) == __float_as_uint(q[2]);
+	};
+	if (same(y.v0, x.v0) && same(y.v1, x.v2)) return 1;
+	if (same(x.v0, y.v0) && same(x.v1, y.v2)) return 2;
+	return 0;
+}
+
+__device__ __forceinline__ bool quadCandidate(uint32_t ref)
+{
+	return (ref & PT_LEAF_FLAG) && ref < PT_INSTANCE_END && ((ref >> 28) & 7u) == 1u;  // a leaf of exactly two triangles
+}
+
+// One thread per child slot: flags[4 * node + c] = 1 if the slot holds a fan pair.
+__global__ void __launch_bounds__(kBlock) k_quad_flag(const PtNode4 *nodes, uint32_t nNodes, const PtTri48 *plane2, uint32_t *flags)
+{
+	const uint32_t i = blockIdx.x * kBlock + threadIdx.x;
+	if (i >= 4u * nNodes) return;
+	const uint32_t ref = nodes[i >> 2].child[i & 3u];
+	uint32_t f = 0;
+	if (quadCandidate(ref))
+	{
+		const uint32_t first = ref & 0x0FFFFFFFu;
+		f = quadPattern(plane2[first], plane2[first + 1]) != 0 ? 1u : 0u;
+	}
+	flags[i] = f;
+}
+
+// index = exclusive scan of the flags.  Writes the quad records (all three planes, from the triangle records of the same
+// plane) and patches the child reference in the copy of the node array.
+__global__ void __launch_bounds__(kBlock)
+    k_quad_write(const PtNode4 *nodes, uint32_t nNodes, const PtTri48 *tris, uint32_t nTris, const uint32_t *index,
+                 PtNode4 *nodesOut, PtQuad64 *quads, uint32_t nQuads)
+{
+	const uint32_t i = blockIdx.x * kBlock + threadIdx.x;
+	if (i >= 4u * nNodes) return;
+	const uint32_t ref = nodes[i >> 2].child[i & 3u];
+	if (!quadCandidate(ref)) return;
+	const uint32_t first = ref & 0x0FFFFFFFu;
+	const PtTri48 *plane2 = tris + 2 * (size_t)nTris;
+	const int pat = quadPattern(plane2[first], plane2[first + 1]);
+	if (pat == 0) return;
+	const uint32_t qi = index[i];
+	if (qi >= nQuads) return;  // cannot happen (the scan counted exactly these slots); keeps a wrong count from writing outside
+	const uint32_t ia = pat == 1 ? first : first + 1, ib = pat == 1 ? first + 1 : first;
+	for (int r = 0; r < 3; ++r)
+	{
+		const PtTri48 a = tris[(size_t)r * nTris + ia], b = tris[(size_t)r * nTris + ib];
+		PtQuad64 q;
+		for (int k = 0; k < 3; ++k)
+		{
+			q.v0[k] = a.v0[k];
+			q.v1[k] = a.v1[k];
+			q.v2[k] = a.v2[k];
+			q.v3[k] = b.v2[k];
+		}
+		q.primA = a.prim;
+		q.primB = b.prim;
+		q.pad[0] = q.pad[1] = 0u;
+		quads[(size_t)r * nQuads + qi] = q;
+	}
+	nodesOut[i >> 2].child[i & 3u] = PT_LEAF_FLAG | (PT_LEAF_QUAD << 28) | qi;
+}
+}  // namespace
+
+hipError_t ptBuildQuadLeaves(const PtNode4 *nodes, uint32_t nNodes, const PtTri48 *tris, uint32_t nTris, float minShare,
+                             PtQuadOutput &out, hipStream_t stream)
+{
+	out = PtQuadOutput();
+	if (!nNodes || nTris < 2 || nNodes > 0x3FFFFFFFu) return hipSuccess;
+	const size_t nSlots = 4 * (size_t)nNodes;
+	uint32_t *flags = nullptr;
+	const size_t words = ((nSlots + 63) & ~(size_t)63) + scanScratchLen(nSlots) + 64;
+	hipError_t e = hipMalloc(&flags, 4 * words);
+	if (e != hipSuccess) return e;
+	uint32_t *scratch = flags + ((nSlots + 63) & ~(size_t)63), *total = flags + words - 64;
+	k_quad_flag<<<divUp((uint32_t)nSlots, kBlock), kBlock, 0, stream>>>(nodes, nNodes, tris + 2 * (size_t)nTris, flags);
+	scanExclusive<uint32_t>(flags, nSlots, scratch, total, stream);  // the grand total comes out of the top level of the recursion
+	uint32_t nQuads = 0;
+	e = hipMemcpyAsync(&nQuads, total, 4, hipMemcpyDeviceToHost, stream);
+	if (e == hipSuccess) e = hipStreamSynchronize(stream);
+	if (e == hipSuccess && nQuads && 2.0 * (double)nQuads >= (double)minShare * (double)nTris)
+	{
+		e = hipMalloc(&out.nodes, sizeof(PtNode4) * (size_t)nNodes);
+		if (e == hipSuccess) e = hipMalloc(&out.quads, sizeof(PtQuad64) * 3 * (size_t)nQuads);
+		if (e == hipSuccess) e = hipMemcpyAsync(out.nodes, nodes, sizeof(PtNode4) * (size_t)nNodes, hipMemcpyDeviceToDevice, stream);
+		if (e == hipSuccess)
+		{
+			k_quad_write<<<divUp((uint32_t)nSlots, kBlock), kBlock, 0, stream>>>(nodes, nNodes, tris, nTris, flags, out.nodes, out.quads,
+			                                                                  nQuads);
+			e = hipStreamSynchronize(stream);
+		}
+		if (e == hipSuccess) e = hipGetLastError();
+		if (e == hipSuccess) out.nQuads = nQuads;
+		else
+		{
+			hipFree(out.nodes);
+			hipFree(out.quads);
+			out = PtQuadOutput();
+		}
+	}
+	hipFree(flags);
+	return e;
+}

@@ -279,6 +279,19 @@ struct __attribute__((aligned(16))) PtTri48
 };
 static_assert(sizeof(PtTri48) == 48, "PtTri48 must be 48 bytes");
 
+// Quad leaf (k_paths only; pt_build.h, ptBuildQuadLeaves): the two triangles (a, b, c), (a, c, d) that a fan-triangulated
+// quad face gives, as four vertices: v0 v1 v2 = triangle A in its own vertex order, triangle B = (v0, v2, v3).  Four
+// 16-byte loads instead of six, four vertex transforms instead of six, and B's third edge function is A's second, negated
+// (exactly: fl(x*y) is commutative and negation is exact), so t, u, v of both triangles keep their bits.
+struct __attribute__((aligned(16))) PtQuad64
+{
+	float v0[3], v1[3], v2[3], v3[3];
+	uint32_t primA, primB;
+	uint32_t pad[2];
+};
+static_assert(sizeof(PtQuad64) == 64, "PtQuad64 must be 64 bytes");
+#define PT_LEAF_QUAD 7u  // count field (count - 1) of a quad leaf reference; such scenes are built with leaves of <= 7 triangles
+
 // Everything raytrace.rchit fetches for one primitive through matIndices -> Material and indices -> 3 x Vertex
 // (rchit:27-37), gathered once at upload into one 96-byte record: six 16-byte loads of one lane instead of ten
 // dependent ones (a divergent-address load in a hot phase costs the frame as much as ~10 VALU instructions,
@@ -304,6 +317,8 @@ struct PtSceneDev
 	const PtTri48 *tris;
 	uint32_t nTris;
 	uint32_t nNodes;
+	const PtQuad64 *quads;  // quad leaves (three planes of nQuads records, rotated like tris) or nullptr
+	uint32_t nQuads;
 	// optional diffuse map (pt_set_texture): texW x texH linear RGBA texels, row 0 = v 0; nullptr = none
 	const float4 *texture;
 	uint32_t texW, texH;

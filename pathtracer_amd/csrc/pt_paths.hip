@@ -536,7 +536,7 @@ __global__ void __launch_bounds__(PT_WAVE) PT_PATHS_OCCUPANCY k_paths(PtPathsArg
 			else
 			{
 				if (kStats && cur != PT_EMPTY_CHILD) ++leafVisits;
-				pt_leaf_step<kStackLds>(sc, ray, tmin, best, cur, sp, sStack, lane, mySpill, a.spillStride, triTests,
+				pt_leaf_step<kStackLds, !kInst>(sc, ray, tmin, best, cur, sp, sStack, lane, mySpill, a.spillStride, triTests,
 				                        kInst ? inst : 0u, kInst ? &bestInst : nullptr);
 			}
 		}

@@ -251,7 +251,8 @@ __device__ __forceinline__ void pt_stack_push(uint32_t v, int &sp, uint32_t (*sS
 
 // curInst / bestInst: instance the lane is inside and instance of the best hit (two-level scenes; ties at equal t
 // go to the lower instance index, then the lower primitive id).  Single-level callers pass 0 and a dummy.
-template <int kStackLds>
+// kQuads: the tree may hold quad leaf references (PtQuad64; k_paths on scenes made of quad faces).
+template <int kStackLds, bool kQuads = false>
 __device__ __forceinline__ void pt_leaf_step(const PtSceneDev &sc, const PtLaneRay &ray, float tmin, PtBest &best,
                                              uint32_t &cur, int &sp, uint32_t (*sStack)[PT_WAVE], int lane,
                                              uint32_t *mySpill, uint32_t spillStride, uint32_t &triTests,
@@ -264,6 +265,38 @@ __device__ __forceinline__ void pt_leaf_step(const PtSceneDev &sc, const PtLaneR
 	uint32_t next = sp < kStackLds ? sStack[sp][lane]
 	                               : (sp < kStackLds + PT_SPILL_STACK ? mySpill[(size_t)(sp - kStackLds) * spillStride]
 	                                                                  : PT_EMPTY_CHILD);
+	// Second half of the Woop/Benthin/Wald watertight test (pt_tri_test without the selects): the edge functions U, V, W of
+	// the sheared vertices (Ax, Ay) (Bx, By) (Cx, Cy), recomputed in double precision when one of them is zero; a hit inside
+	// the triangle replaces the best one when it is closer, or equally far with the lower primitive (instance) id.
+	auto finish = [&](float U, float V, float W, float Ax, float Ay, float Akz, float Bx, float By, float Bkz, float Cx, float Cy,
+	                  float Ckz, uint32_t prim) {
+		if (U == 0.0f || V == 0.0f || W == 0.0f)
+		{
+			U = (float)((double)Cx * (double)By - (double)Cy * (double)Bx);
+			V = (float)((double)Ax * (double)Cy - (double)Ay * (double)Cx);
+			W = (float)((double)Bx * (double)Ay - (double)By * (double)Ax);
+		}
+		bool anyNeg = U < 0.0f || V < 0.0f || W < 0.0f, anyPos = U > 0.0f || V > 0.0f || W > 0.0f;
+		float det = (U + V) + W;
+		if (!(anyNeg && anyPos) && det != 0.0f)
+		{
+			float Az = Sz * Akz, Bz = Sz * Bkz, Cz = Sz * Ckz;
+			float T = (U * Az + V * Bz) + W * Cz;
+			float t = T / det;
+			bool tie = t == best.t && best.prim != PT_NO_HIT;
+			if (bestInst) tie = tie && (curInst < *bestInst || (curInst == *bestInst && prim < best.prim));
+			else tie = tie && prim < best.prim;
+			if (t > tmin && (t < best.t || tie))
+			{
+				if (bestInst) *bestInst = curInst;
+				best.t = t;
+				best.prim = prim;
+				best.V = V;
+				best.W = W;
+				best.det = det;
+			}
+		}
+	};
 	if (cur != PT_EMPTY_CHILD)
 	{
 		const uint32_t kz = kpack & 3u;
@@ -272,49 +305,52 @@ __device__ __forceinline__ void pt_leaf_step(const PtSceneDev &sc, const PtLaneR
 		float roy = kz == 0 ? oz : (kz == 1 ? ox : oy);
 		float roz = kz == 0 ? ox : (kz == 1 ? oy : oz);
 		uint32_t first = cur & 0x0FFFFFFFu;
-		uint32_t cnt = ((cur >> 28) & 7u) + 1u;
-		triTests += cnt;
-		const float4 *tp = reinterpret_cast<const float4 *>(sc.tris + (size_t)kz * sc.nTris + first);
-		for (uint32_t i = 0; i < cnt; ++i, tp += 3)
+		const bool quad = kQuads && ((cur >> 28) & 7u) == PT_LEAF_QUAD;
+		if (!quad)
 		{
-			float4 a = tp[0], b = tp[1], c = tp[2];
-			// Woop/Benthin/Wald watertight test in the rotated frame (pt_tri_test without the selects)
-			float Akx = a.x - rox, Aky = a.y - roy, Akz = a.z - roz;
-			float Bkx = a.w - rox, Bky = b.x - roy, Bkz = b.y - roz;
-			float Ckx = b.z - rox, Cky = b.w - roy, Ckz = c.x - roz;
-			float Ax = Akx - Sx * Akz, Ay = Aky - Sy * Akz;
-			float Bx = Bkx - Sx * Bkz, By = Bky - Sy * Bkz;
-			float Cx = Ckx - Sx * Ckz, Cy = Cky - Sy * Ckz;
-			float U = Cx * By - Cy * Bx;
-			float V = Ax * Cy - Ay * Cx;
-			float W = Bx * Ay - By * Ax;
-			if (U == 0.0f || V == 0.0f || W == 0.0f)
+			uint32_t cnt = ((cur >> 28) & 7u) + 1u;
+			triTests += cnt;
+			const float4 *tp = reinterpret_cast<const float4 *>(sc.tris + (size_t)kz * sc.nTris + first);
+			for (uint32_t i = 0; i < cnt; ++i, tp += 3)
 			{
-				U = (float)((double)Cx * (double)By - (double)Cy * (double)Bx);
-				V = (float)((double)Ax * (double)Cy - (double)Ay * (double)Cx);
-				W = (float)((double)Bx * (double)Ay - (double)By * (double)Ax);
+				float4 a = tp[0], b = tp[1], c = tp[2];
+				float Akx = a.x - rox, Aky = a.y - roy, Akz = a.z - roz;
+				float Bkx = a.w - rox, Bky = b.x - roy, Bkz = b.y - roz;
+				float Ckx = b.z - rox, Cky = b.w - roy, Ckz = c.x - roz;
+				float Ax = Akx - Sx * Akz, Ay = Aky - Sy * Akz;
+				float Bx = Bkx - Sx * Bkz, By = Bky - Sy * Bkz;
+				float Cx = Ckx - Sx * Ckz, Cy = Cky - Sy * Ckz;
+				float U = Cx * By - Cy * Bx;
+				float V = Ax * Cy - Ay * Cx;
+				float W = Bx * Ay - By * Ax;
+				finish(U, V, W, Ax, Ay, Akz, Bx, By, Bkz, Cx, Cy, Ckz, __float_as_uint(c.y));
 			}
-			bool anyNeg = U < 0.0f || V < 0.0f || W < 0.0f, anyPos = U > 0.0f || V > 0.0f || W > 0.0f;
-			float det = (U + V) + W;
-			if (!(anyNeg && anyPos) && det != 0.0f)
-			{
-				float Az = Sz * Akz, Bz = Sz * Bkz, Cz = Sz * Ckz;
-				float T = (U * Az + V * Bz) + W * Cz;
-				float t = T / det;
-				uint32_t prim = __float_as_uint(c.y);
-				bool tie = t == best.t && best.prim != PT_NO_HIT;
-				if (bestInst) tie = tie && (curInst < *bestInst || (curInst == *bestInst && prim < best.prim));
-				else tie = tie && prim < best.prim;
-				if (t > tmin && (t < best.t || tie))
-				{
-					if (bestInst) *bestInst = curInst;
-					best.t = t;
-					best.prim = prim;
-					best.V = V;
-					best.W = W;
-					best.det = det;
-				}
-			}
+		}
+		else
+		{
+			// quad leaf: triangle A = (v0, v1, v2), triangle B = (v0, v2, v3); four vertices sheared once
+			triTests += 2u;
+			const float4 *qp = reinterpret_cast<const float4 *>(sc.quads + (size_t)kz * sc.nQuads + first);
+			const float4 a = qp[0], b = qp[1], c = qp[2];
+			const uint2 prims = *reinterpret_cast<const uint2 *>(qp + 3);
+			float P0x = a.x - rox, P0y = a.y - roy, P0z = a.z - roz;
+			float P1x = a.w - rox, P1y = b.x - roy, P1z = b.y - roz;
+			float P2x = b.z - rox, P2y = b.w - roy, P2z = c.x - roz;
+			float P3x = c.y - rox, P3y = c.z - roy, P3z = c.w - roz;
+			float X0 = P0x - Sx * P0z, Y0 = P0y - Sy * P0z;
+			float X1 = P1x - Sx * P1z, Y1 = P1y - Sy * P1z;
+			float X2 = P2x - Sx * P2z, Y2 = P2y - Sy * P2z;
+			float X3 = P3x - Sx * P3z, Y3 = P3y - Sy * P3z;
+			// A: (A, B, C) = (0, 1, 2)
+			float UA = X2 * Y1 - Y2 * X1;
+			float VA = X0 * Y2 - Y0 * X2;
+			float WA = X1 * Y0 - Y1 * X0;
+			// B: (A, B, C) = (0, 2, 3): W = Bx*Ay - By*Ax = X2*Y0 - Y2*X0 = -(X0*Y2 - Y0*X2) = -VA, bit for bit
+			float UB = X3 * Y2 - Y3 * X2;
+			float VB = X0 * Y3 - Y0 * X3;
+			float WB = -VA;
+			finish(UA, VA, WA, X0, Y0, P0z, X1, Y1, P1z, X2, Y2, P2z, prims.x);
+			finish(UB, VB, WB, X0, Y0, P0z, X2, Y2, P2z, X3, Y3, P3z, prims.y);
 		}
 	}
 	cur = next;

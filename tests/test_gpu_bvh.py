@@ -3,6 +3,8 @@ hit-for-hit agreement of its traversal with the brute-force definition on incohe
 import numpy as np
 import pytest
 
+from conftest import bits
+
 pytestmark = pytest.mark.gpu
 
 LEAF = 0x80000000
@@ -162,3 +164,86 @@ def test_compaction_shrinks_the_node_array_and_changes_nothing_else(rt, pa, O):
     assert b.accel_bytes == sc.n_tris * (3 * 48 + 8) + b.bvh_nodes * 64 < 0.85 * b.accel_bytes_uncompacted
     assert np.array_equal(hits_a.view(np.uint32), hits_b.view(np.uint32))
     assert len(nodes_a) == len(nodes_b) == b.bvh_nodes
+
+
+def _quad_mesh(nx, nz, reverse_every=0, drop_every=0, seed=0):
+    """nx * nz separate quad faces (tiles on a jittered grid, tilted), every face fan-triangulated as an OBJ loader does:
+    (a, b, c), (a, c, d).  reverse_every: every k-th face lists its second triangle first; drop_every: every k-th
+    face keeps one triangle only.  An emissive quad hangs above."""
+    rng = np.random.default_rng(seed)
+    F = nx * nz
+    verts = np.zeros((4 * F + 4, 11), dtype=np.float32)
+    idx, face = [], 0
+    for j in range(nz):
+        for i in range(nx):
+            cx = -1.0 + 2.0 * (i + 0.5) / nx + rng.uniform(-0.1, 0.1) / nx
+            cz = -1.0 + 2.0 * (j + 0.5) / nz + rng.uniform(-0.1, 0.1) / nz
+            cy = rng.uniform(0.0, 0.3)
+            hx, hz = 0.7 / nx, 0.7 / nz
+            tilt = rng.uniform(-0.3, 0.3, size=4) * min(hx, hz)
+            base = 4 * face
+            corners = [(-hx, -hz), (hx, -hz), (hx, hz), (-hx, hz)]
+            for k, (dx, dz) in enumerate(corners):
+                verts[base + k, 0:3] = (cx + dx, cy + tilt[k], cz + dz)
+                verts[base + k, 3:6] = (0, 1, 0)
+            t1, t2 = [base, base + 1, base + 2], [base, base + 2, base + 3]
+            face += 1
+            if drop_every and face % drop_every == 0:
+                idx += t1
+            elif reverse_every and face % reverse_every == 0:
+                idx += t2 + t1
+            else:
+                idx += t1 + t2
+    nv = 4 * F
+    verts[nv:, 0:3] = [[-0.5, 1.5, -0.5], [0.5, 1.5, -0.5], [0.5, 1.5, 0.5], [-0.5, 1.5, 0.5]]
+    verts[nv:, 3:6] = (0, -1, 0)
+    verts[:, 6:9] = 1.0
+    n_ground = len(idx) // 3
+    idx += [nv, nv + 1, nv + 2, nv, nv + 2, nv + 3]
+    mats = np.array([[0.7, 0.6, 0.5, 0, 0, 0], [0, 0, 0, 15, 15, 15]], dtype=np.float32)
+    mid = np.concatenate([np.zeros(n_ground, np.uint32), np.ones(2, np.uint32)])
+    return verts, np.array(idx, np.uint32), mats, mid
+
+
+@pytest.mark.parametrize("nx,nz,reverse_every,drop_every", [(3, 2, 0, 0), (12, 9, 2, 0), (40, 31, 3, 17), (9, 9, 0, 2)])
+def test_quad_leaves_bit_exact(rt, pa, O, nx, nz, reverse_every, drop_every):
+    """Scenes made of fan-triangulated quad faces are traversed through quad leaves by the persistent pipeline
+    (PtQuad64): both triangle orders inside a leaf, lone triangles among the quads, and a scene with too few quads to
+    switch the format on; image, ray count, node visits and triangle tests against the oracle / the fused pipeline."""
+    from pathtracer_amd.api import PT_PROFILE_TRAVERSAL
+    v, i, m, mi = _quad_mesh(nx, nz, reverse_every, drop_every, seed=nx)
+    sc = pa.Scene(v, i, m, mi)
+    osc = O.OracleScene(sc.vertices, sc.indices, sc.materials, sc.mat_indices)
+    W, H = 128, 72
+    view = pa.look_at((0.2, 1.3, 2.4), (0.0, 0.2, 0.0), (0, 1, 0))
+    proj = pa.perspective(np.radians(50.0), W / H, 0.1, 100.0)
+    proj[5] *= -1
+    want, rays = osc.render(view, proj, W, H, frames=2, spp_per_frame=3, max_depth=6, seed=5)
+    quads = []
+    for builder in (pa.api.PT_ACCEL_BVH4, pa.api.PT_ACCEL_BVH4_PLOC):
+        rt.uploadScene(sc)
+        rt.buildBlas(None, builder)
+        st = rt.stats()
+        quads.append(st.quad_leaves)
+        if drop_every == 2:
+            assert st.quad_leaves == 0  # half of the faces are lone triangles: below the 90 % share
+        rt.resize(W, H)
+        rt.setCamera(view, proj)
+        rt.setParams(spp_per_frame=3, max_depth=6, seed=5)
+        trav = {}
+        for name, mode in (("persistent", 2), ("fused", 0)):
+            rt.setPipeline(mode)
+            for prof in (0, PT_PROFILE_TRAVERSAL):
+                rt.setProfiling(prof)
+                rt.resetFrame()
+                rt.resetStats()
+                rt.raytrace(2)
+                s2 = rt.stats()
+                assert s2.rays_total == rays, (name, prof)
+                assert np.array_equal(bits(rt.readImage()), bits(want)), (name, prof, builder)
+            trav[name] = (s2.trav_nodes, s2.trav_tris, s2.trav_hits)
+        rt.setProfiling(0)
+        assert trav["persistent"] == trav["fused"], trav
+    print("quad leaves (lbvh, ploc):", quads, "of", sc.n_tris // 2, "faces")
+    if drop_every != 2:
+        assert max(quads) > 0, quads  # at least one builder keeps the faces together
