@@ -265,11 +265,10 @@ __device__ __forceinline__ void pt_leaf_step(const PtSceneDev &sc, const PtLaneR
 	uint32_t next = sp < kStackLds ? sStack[sp][lane]
 	                               : (sp < kStackLds + PT_SPILL_STACK ? mySpill[(size_t)(sp - kStackLds) * spillStride]
 	                                                                  : PT_EMPTY_CHILD);
-	// Second half of the Woop/Benthin/Wald watertight test (pt_tri_test without the selects): the edge functions U, V, W of
-	// the sheared vertices (Ax, Ay) (Bx, By) (Cx, Cy), recomputed in double precision when one of them is zero; a hit inside
-	// the triangle replaces the best one when it is closer, or equally far with the lower primitive (instance) id.
-	auto finish = [&](float U, float V, float W, float Ax, float Ay, float Akz, float Bx, float By, float Bkz, float Cx, float Cy,
-	                  float Ckz, uint32_t prim) {
+	// Second half of the Woop/Benthin/Wald watertight test (pt_tri_test without the selects), in two parts.
+	// inside(): the edge functions U, V, W of the sheared vertices (Ax, Ay) (Bx, By) (Cx, Cy) are recomputed in double
+	// precision when one of them is zero; true when the ray passes inside the triangle (det = U + V + W, not zero).
+	auto inside = [](float &U, float &V, float &W, float &det, float Ax, float Ay, float Bx, float By, float Cx, float Cy) {
 		if (U == 0.0f || V == 0.0f || W == 0.0f)
 		{
 			U = (float)((double)Cx * (double)By - (double)Cy * (double)Bx);
@@ -277,24 +276,26 @@ __device__ __forceinline__ void pt_leaf_step(const PtSceneDev &sc, const PtLaneR
 			W = (float)((double)Bx * (double)Ay - (double)By * (double)Ax);
 		}
 		bool anyNeg = U < 0.0f || V < 0.0f || W < 0.0f, anyPos = U > 0.0f || V > 0.0f || W > 0.0f;
-		float det = (U + V) + W;
-		if (!(anyNeg && anyPos) && det != 0.0f)
+		det = (U + V) + W;
+		return !(anyNeg && anyPos) && det != 0.0f;
+	};
+	// accept(): distance of the hit; it replaces the best one when it is closer, or equally far with the lower primitive
+	// (instance) id.
+	auto accept = [&](float U, float V, float W, float det, float Akz, float Bkz, float Ckz, uint32_t prim) {
+		float Az = Sz * Akz, Bz = Sz * Bkz, Cz = Sz * Ckz;
+		float T = (U * Az + V * Bz) + W * Cz;
+		float t = T / det;
+		bool tie = t == best.t && best.prim != PT_NO_HIT;
+		if (bestInst) tie = tie && (curInst < *bestInst || (curInst == *bestInst && prim < best.prim));
+		else tie = tie && prim < best.prim;
+		if (t > tmin && (t < best.t || tie))
 		{
-			float Az = Sz * Akz, Bz = Sz * Bkz, Cz = Sz * Ckz;
-			float T = (U * Az + V * Bz) + W * Cz;
-			float t = T / det;
-			bool tie = t == best.t && best.prim != PT_NO_HIT;
-			if (bestInst) tie = tie && (curInst < *bestInst || (curInst == *bestInst && prim < best.prim));
-			else tie = tie && prim < best.prim;
-			if (t > tmin && (t < best.t || tie))
-			{
-				if (bestInst) *bestInst = curInst;
-				best.t = t;
-				best.prim = prim;
-				best.V = V;
-				best.W = W;
-				best.det = det;
-			}
+			if (bestInst) *bestInst = curInst;
+			best.t = t;
+			best.prim = prim;
+			best.V = V;
+			best.W = W;
+			best.det = det;
 		}
 	};
 	if (cur != PT_EMPTY_CHILD)
@@ -323,7 +324,8 @@ __device__ __forceinline__ void pt_leaf_step(const PtSceneDev &sc, const PtLaneR
 				float U = Cx * By - Cy * Bx;
 				float V = Ax * Cy - Ay * Cx;
 				float W = Bx * Ay - By * Ax;
-				finish(U, V, W, Ax, Ay, Akz, Bx, By, Bkz, Cx, Cy, Ckz, __float_as_uint(c.y));
+				float det;
+				if (inside(U, V, W, det, Ax, Ay, Bx, By, Cx, Cy)) accept(U, V, W, det, Akz, Bkz, Ckz, __float_as_uint(c.y));
 			}
 		}
 		else
@@ -349,8 +351,15 @@ __device__ __forceinline__ void pt_leaf_step(const PtSceneDev &sc, const PtLaneR
 			float UB = X3 * Y2 - Y3 * X2;
 			float VB = X0 * Y3 - Y0 * X3;
 			float WB = -VA;
-			finish(UA, VA, WA, X0, Y0, P0z, X1, Y1, P1z, X2, Y2, P2z, prims.x);
-			finish(UB, VB, WB, X0, Y0, P0z, X2, Y2, P2z, X3, Y3, P3z, prims.y);
+			float detA, detB;
+			const bool inA = inside(UA, VA, WA, detA, X0, Y0, X1, Y1, X2, Y2);
+			const bool inB = inside(UB, VB, WB, detB, X0, Y0, X2, Y2, X3, Y3);
+			// a ray is inside at most one of the two (both only on the shared edge or across a folded quad): one pass through
+			// the distance arithmetic with A's or B's operands selected, and a second one for the rare lane inside both
+			if (inA || inB)
+				accept(inA ? UA : UB, inA ? VA : VB, inA ? WA : WB, inA ? detA : detB, P0z, inA ? P1z : P2z, inA ? P2z : P3z,
+				       inA ? prims.x : prims.y);
+			if (inA && inB) accept(UB, VB, WB, detB, P0z, P2z, P3z, prims.y);
 		}
 	}
 	cur = next;
