@@ -706,6 +706,7 @@ extern "C" int pt_set_camera(pt_ctx *c, const float view[16], const float proj[1
 	PtCamera cam;
 	pt_inverse4(view, cam.invView);
 	pt_inverse4(proj, cam.invProj);
+	pt_camera_fill_constants(cam);
 	// VulkanRaytracing::updateFrame's stated intent ("Resets the frame counter if the camera has changed",
 	// VulkanRaytracing.cpp:903-908, left as a TODO there): a different camera restarts the accumulation; the same
 	// matrices again (main.cpp calls updateUniformBuffer every frame) change nothing.

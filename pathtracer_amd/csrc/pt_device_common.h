@@ -100,7 +100,27 @@ struct PtCamera
 {
 	float invView[16];
 	float invProj[16];
+	// the ray-independent parts of raytrace.rgen:40-46, evaluated once on the host with the same float expressions
+	// (pt_camera_fill_constants): origin = invView * (0,0,0,1); projConst[k] = P[8+k]*1 + P[12+k]*1; viewZero[k] = V[12+k]*0
+	float origin[3];
+	float projConst[3];
+	float viewZero[3];
+	float pad[3];
 };
+static_assert(sizeof(PtCamera) == 44 * 4, "PtCamera is 44 floats");
+
+// Host and device: the constant sub-expressions of pt_camera_ray_from, in its association and precision.
+__host__ __device__ inline void pt_camera_fill_constants(PtCamera &cam)
+{
+	const float *V = cam.invView, *P = cam.invProj;
+	for (int k = 0; k < 3; ++k)
+	{
+		cam.origin[k] = (V[0 + k] * 0.0f + V[4 + k] * 0.0f) + (V[8 + k] * 0.0f + V[12 + k] * 1.0f);
+		cam.projConst[k] = P[8 + k] * 1.0f + P[12 + k] * 1.0f;
+		cam.viewZero[k] = V[12 + k] * 0.0f;
+		cam.pad[k] = 0.0f;
+	}
+}
 
 // raytrace.rgen:40-46 with inverse(view)/inverse(proj) hoisted to the host.  Matrix * vector in
 // glm's association: (m0*x + m1*y) + (m2*z + m3*w).  V, P: the two inverse matrices (column-major), through any pointer type.
@@ -123,6 +143,29 @@ __device__ __forceinline__ void pt_camera_ray_from(FP V, FP P, uint32_t W, uint3
 	d.x = (V[0] * n.x + V[4] * n.y) + (V[8] * n.z + V[12] * 0.0f);
 	d.y = (V[1] * n.x + V[5] * n.y) + (V[9] * n.z + V[13] * 0.0f);
 	d.z = (V[2] * n.x + V[6] * n.y) + (V[10] * n.z + V[14] * 0.0f);
+}
+
+// The same ray from a PtCamera behind `c` whose constants are filled in (k_paths: 44 floats in device memory).
+template <typename FP>
+__device__ __forceinline__ void pt_camera_ray_const(FP c, uint32_t W, uint32_t H, uint32_t px, uint32_t py, float jx, float jy,
+                                                    float3x &o, float3x &d)
+{
+	FP V = c, P = c + 16;
+	float uvx = ((float)px + jx) / (float)W;
+	float uvy = ((float)py + jy) / (float)H;
+	float dx = uvx * 2.0f - 1.0f;
+	float dy = uvy * 2.0f - 1.0f;
+	o.x = c[32];
+	o.y = c[33];
+	o.z = c[34];
+	float3x t;
+	t.x = (P[0] * dx + P[4] * dy) + c[35];
+	t.y = (P[1] * dx + P[5] * dy) + c[36];
+	t.z = (P[2] * dx + P[6] * dy) + c[37];
+	float3x n = pt_normalize(t);
+	d.x = (V[0] * n.x + V[4] * n.y) + (V[8] * n.z + c[38]);
+	d.y = (V[1] * n.x + V[5] * n.y) + (V[9] * n.z + c[39]);
+	d.z = (V[2] * n.x + V[6] * n.y) + (V[10] * n.z + c[40]);
 }
 
 __device__ __forceinline__ void pt_camera_ray(const PtCamera &cam, uint32_t W, uint32_t H, uint32_t px, uint32_t py,

@@ -375,7 +375,7 @@ __global__ void __launch_bounds__(PT_WAVE) PT_PATHS_OCCUPANCY k_paths(PtPathsArg
 							unsigned long long camAddr = reinterpret_cast<unsigned long long>(PT_COLD(cam));
 							asm volatile("" : "+s"(camAddr));
 							pt_const_float *cm = reinterpret_cast<pt_const_float *>(camAddr);
-							pt_camera_ray_from<pt_const_float *>(cm, cm + 16, PT_COLD(W), PT_COLD(H), genPx, genPy, jx, jy, o, d);
+							pt_camera_ray_const<pt_const_float *>(cm, PT_COLD(W), PT_COLD(H), genPx, genPy, jx, jy, o, d);
 							uint32_t pq = item * PT_WAVE + lane;
 							// payload.seed = seed: the bounce stream starts from the state after the two jitter
 							// draws, while the raygen-local seed continues from the same state for the next sample
@@ -610,8 +610,8 @@ namespace
 {
 __global__ void k_store_camera(PtCamera cam, PtCamera *dst)
 {
-	const float *src = cam.invView;  // invView and invProj are contiguous: 32 floats
-	if (threadIdx.x < 32) dst->invView[threadIdx.x] = src[threadIdx.x];
+	const float *src = cam.invView;  // the struct is 44 contiguous floats
+	if (threadIdx.x < sizeof(PtCamera) / 4) dst->invView[threadIdx.x] = src[threadIdx.x];
 }
 }  // namespace
 
