@@ -230,7 +230,7 @@ __global__ void __launch_bounds__(PT_WAVE) PT_PATHS_OCCUPANCY k_paths(PtPathsArg
 
 	// Writes lane's prepared ray into the staging area.
 	auto stage = [&](float3x o, float3x d, uint32_t depth, uint32_t pq) {
-		PtLaneRay pr = pt_prepare_ray(o, d);
+		PtLaneRay pr = pt_prepare_ray<true>(o, d);  // every lane of the staging batch is here: the shared-reciprocal form
 		sIn[0][lane] = __float_as_uint(pr.ox);
 		sIn[1][lane] = __float_as_uint(pr.oy);
 		sIn[2][lane] = __float_as_uint(pr.oz);

@@ -16,6 +16,7 @@ struct PtLaneRay
 // Prepares a ray for traversal (runs at full lane utilisation in the staging phase: the divisions live here).
 // Woop's winding swap for d[kz] < 0 is omitted: it negates U, V, W, det and T exactly and leaves t, u, v
 // unchanged, so results equal the oracle's (which keeps the swap) bit for bit.
+template <bool kShareReciprocal = false>
 __device__ __forceinline__ PtLaneRay pt_prepare_ray(float3x o, float3x d)
 {
 	PtLaneRay r;
@@ -31,9 +32,42 @@ __device__ __forceinline__ PtLaneRay pt_prepare_ray(float3x o, float3x d)
 	float dkz = kz == 0 ? d.x : (kz == 1 ? d.y : d.z);
 	float dkx = kz == 0 ? d.y : (kz == 1 ? d.z : d.x);
 	float dky = kz == 0 ? d.z : (kz == 1 ? d.x : d.y);
-	r.Sx = dkx / dkz;
-	r.Sy = dky / dkz;
-	r.Sz = 1.0f / dkz;
+	// Three IEEE divisions by the same number.  hipcc expands each into v_div_scale x2, v_rcp, two Newton steps on the
+	// reciprocal, three on the quotient, v_div_fmas, v_div_fixup (11 instructions); the reciprocal part depends on the
+	// denominator only.  When every lane's operands are far from the exponent limits (|dkz| and the non-zero numerators within
+	// 2^+-30: then v_div_scale scales nothing, v_div_fmas is a plain fma and v_div_fixup returns its input) the same
+	// instructions are issued with that part shared -- 18 instead of 33, bit-identical quotients; otherwise, and always where
+	// lanes call this one by one (kShareReciprocal == false), the plain divisions.
+	bool shared = false;
+	if (kShareReciprocal)
+	{
+		const float lo = 9.31322575e-10f, hi = 1073741824.0f;  // 2^-30, 2^30
+		const float ax = fabsf(dkx), ay = fabsf(dky), az = fabsf(dkz);
+		const bool ok = az >= lo && az <= hi && ax >= lo && ax <= hi && ay >= lo && ay <= hi;
+		shared = __builtin_amdgcn_ballot_w64(!ok) == 0ull;  // wave-uniform
+	}
+	if (shared)
+	{
+		float rc = __builtin_amdgcn_rcpf(dkz);
+		float e0 = __builtin_fmaf(-dkz, rc, 1.0f);
+		rc = __builtin_fmaf(e0, rc, rc);
+		auto quotient = [&](float n) {
+			float q = n * rc;
+			float e = __builtin_fmaf(-dkz, q, n);
+			q = __builtin_fmaf(e, rc, q);
+			e = __builtin_fmaf(-dkz, q, n);
+			return __builtin_fmaf(e, rc, q);
+		};
+		r.Sx = quotient(dkx);
+		r.Sy = quotient(dky);
+		r.Sz = quotient(1.0f);
+	}
+	else
+	{
+		r.Sx = dkx / dkz;
+		r.Sy = dky / dkz;
+		r.Sz = 1.0f / dkz;
+	}
 	// box test only: zero components nudged so that 0 * inf cannot occur (interval stays huge)
 	float dcx = fabsf(d.x) > 1e-30f ? d.x : copysignf(1e-30f, d.x);
 	float dcy = fabsf(d.y) > 1e-30f ? d.y : copysignf(1e-30f, d.y);
