@@ -77,21 +77,83 @@ __device__ __forceinline__ void pt_sincos_2pi(float u, float &s_out, float &c_ou
 	c_out = (((q + 1) & 2) ? -cc : cc);
 }
 
-// shaders/random.glsl:59-64 (theta draw first, then z)
+// ---- IEEE sqrt, reciprocal and division, in-range forms ----
+// hipcc expands __builtin_sqrtf into: scale x by 2^32 if it is tiny, v_sqrt_f32, one correction step to the correctly
+// rounded root (the neighbours one ulp below and above are tried against x with an fma each), scale back, pass 0 / inf
+// through -- 16 instructions; and n / d into v_div_scale x2, v_rcp_f32, two Newton steps on the reciprocal, three on
+// the quotient, v_div_fmas, v_div_fixup -- 11.  For operands far from the exponent limits the scaling, the fix-up and the
+// class check are identities; the functions below are the remaining instructions, in the same order, so they return the
+// same bits.  Callers use them only when a wave-uniform range check has passed for every active lane, and fall back to the
+// plain operators otherwise.
+__device__ __forceinline__ float pt_sqrt_in_range(float x)
+{
+	float s = __builtin_amdgcn_sqrtf(x);
+	float below = __uint_as_float(__float_as_uint(s) - 1u), above = __uint_as_float(__float_as_uint(s) + 1u);
+	float rb = __builtin_fmaf(-below, s, x);
+	float ra = __builtin_fmaf(-above, s, x);
+	float r = (0.0f >= rb) ? below : s;
+	return (0.0f < ra) ? above : r;
+}
+// n / d for several numerators and one denominator: the reciprocal part of the expansion is computed once
+struct PtSharedDivisor
+{
+	float d, rc;
+	__device__ __forceinline__ explicit PtSharedDivisor(float den) : d(den)
+	{
+		rc = __builtin_amdgcn_rcpf(den);
+		float e = __builtin_fmaf(-den, rc, 1.0f);
+		rc = __builtin_fmaf(e, rc, rc);
+	}
+	__device__ __forceinline__ float quotient(float n) const
+	{
+		float q = n * rc;
+		float e = __builtin_fmaf(-d, q, n);
+		q = __builtin_fmaf(e, rc, q);
+		e = __builtin_fmaf(-d, q, n);
+		return __builtin_fmaf(e, rc, q);
+	}
+};
+// true when |a|, |b|, |c| all lie in [2^-40, 2^40] for every active lane of the wave (quotients of two such numbers stay
+// 2^46 away from the exponent limits: no scaling in v_div_scale, nothing to fix in v_div_fixup; a NaN fails the test)
+__device__ __forceinline__ bool pt_all_in_division_range(float a, float b, float c)
+{
+	const float lo = 9.09494702e-13f, hi = 1.09951163e12f;
+	const float x = fabsf(a), y = fabsf(b), z = fabsf(c);
+	const bool ok = x >= lo && x <= hi && y >= lo && y <= hi && z >= lo && z <= hi;
+	return __builtin_amdgcn_ballot_w64(!ok) == 0ull;
+}
+// true when |x| lies in [2^-60, 2^60] for every active lane of the wave
+__device__ __forceinline__ bool pt_all_in_range(float x)
+{
+	const float a = fabsf(x);
+	const bool ok = a >= 8.67361738e-19f && a <= 1.15292150e18f;
+	return __builtin_amdgcn_ballot_w64(!ok) == 0ull;
+}
+
+// shaders/random.glsl:59-64 (theta draw first, then z).  kInRange: called by all lanes of a full shading pass (k_paths):
+// the in-range sqrt when it applies to every one of them.
+template <bool kInRange = false>
 __device__ __forceinline__ float3x pt_rnd_unit_vector(uint32_t &prev)
 {
 	float u = pt_rnd(prev);
 	float z = pt_rnd(prev) * 2.0f - 1.0f;
-	float r = __builtin_sqrtf(1.0f - z * z);
+	float x = 1.0f - z * z;
+	float r;
+	if (kInRange && pt_all_in_range(x)) r = pt_sqrt_in_range(x);
+	else r = __builtin_sqrtf(x);
 	float s, c;
 	pt_sincos_2pi(u, s, c);
 	return { r * c, r * s, z };
 }
 
 // glm-style normalize: v * (1 / sqrt((x*x + y*y) + z*z))
+template <bool kInRange = false>
 __device__ __forceinline__ float3x pt_normalize(float3x v)
 {
-	float inv = 1.0f / __builtin_sqrtf((v.x * v.x + v.y * v.y) + v.z * v.z);
+	float x = (v.x * v.x + v.y * v.y) + v.z * v.z;
+	float inv;
+	if (kInRange && pt_all_in_range(x)) inv = PtSharedDivisor(pt_sqrt_in_range(x)).quotient(1.0f);
+	else inv = 1.0f / __builtin_sqrtf(x);
 	return { v.x * inv, v.y * inv, v.z * inv };
 }
 
@@ -162,7 +224,7 @@ __device__ __forceinline__ void pt_camera_ray_const(FP c, uint32_t W, uint32_t H
 	t.x = (P[0] * dx + P[4] * dy) + c[35];
 	t.y = (P[1] * dx + P[5] * dy) + c[36];
 	t.z = (P[2] * dx + P[6] * dy) + c[37];
-	float3x n = pt_normalize(t);
+	float3x n = pt_normalize<true>(t);  // k_paths: every valid lane of the item generates here
 	d.x = (V[0] * n.x + V[4] * n.y) + (V[8] * n.z + c[38]);
 	d.y = (V[1] * n.x + V[5] * n.y) + (V[9] * n.z + c[39]);
 	d.z = (V[2] * n.x + V[6] * n.y) + (V[10] * n.z + c[40]);
@@ -399,6 +461,7 @@ __device__ __forceinline__ float3x pt_sample_texture(const float4 *tex, uint32_t
 // (c0*x + c1*y) + (c2*z + c3*1); worldHitNormal = normalize(vec3(localHitNormal * gl_WorldToObjectEXT)), a row
 // vector times the matrix.  xf == nullptr is the reference's single identity instance (no transform arithmetic).
 // kd = hitValue of rchit:54 (the material's diffuse colour, times the diffuse map when the scene has one), ke = emission.
+template <bool kInRange = false>
 __device__ __forceinline__ void pt_shade_hit(const PtSceneDev &sc, uint32_t prim, float u, float v, uint32_t &seed,
                                          float3x &o, float3x &d, float3x &kd, float3x &ke, const float *xf = nullptr)
 {
@@ -454,9 +517,9 @@ __device__ __forceinline__ void pt_shade_hit(const PtSceneDev &sc, uint32_t prim
 		P = Pw;
 		N = Nw;
 	}
-	float3x Nn = pt_normalize(N);
-	float3x rv = pt_rnd_unit_vector(seed);
-	d = pt_normalize({ Nn.x + rv.x, Nn.y + rv.y, Nn.z + rv.z });
+	float3x Nn = pt_normalize<kInRange>(N);
+	float3x rv = pt_rnd_unit_vector<kInRange>(seed);
+	d = pt_normalize<kInRange>({ Nn.x + rv.x, Nn.y + rv.y, Nn.z + rv.z });
 	o = P;
 }
 

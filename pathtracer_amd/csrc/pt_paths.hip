@@ -195,11 +195,22 @@ __global__ void __launch_bounds__(PT_WAVE) PT_PATHS_OCCUPANCY k_paths(PtPathsArg
 			if (prim != PT_NO_HIT)  // rmiss: hitValue = 0, emission = 0, terminate -> nothing to do
 			{
 				float V = __uint_as_float(sDone[0][e]), W = __uint_as_float(sDone[1][e]), det = __uint_as_float(sDone[2][e]);
-				float u = V / det, v = W / det;
+				float u, v;
+				if (pt_all_in_division_range(det, V, W))  // same quotients, the reciprocal refined once (pt_device_common.h)
+				{
+					const PtSharedDivisor by(det);
+					u = by.quotient(V);
+					v = by.quotient(W);
+				}
+				else
+				{
+					u = V / det;
+					v = W / det;
+				}
 				float4 T = a.state[pq];  // throughput, rng state
 				uint32_t seed = __float_as_uint(T.w);
 				float3x kd, ke;
-				pt_shade_hit(fsc, prim, u, v, seed, no, nd, kd, ke,
+				pt_shade_hit<true>(fsc, prim, u, v, seed, no, nd, kd, ke,
 				             kInst ? a.instances + 24 * (size_t)sDone[kDoneFields][e] : nullptr);
 				float ex = ke.x, ey = ke.y, ez = ke.z;
 				if (ex != 0.0f || ey != 0.0f || ez != 0.0f)

@@ -34,33 +34,16 @@ __device__ __forceinline__ PtLaneRay pt_prepare_ray(float3x o, float3x d)
 	float dky = kz == 0 ? d.z : (kz == 1 ? d.x : d.y);
 	// Three IEEE divisions by the same number.  hipcc expands each into v_div_scale x2, v_rcp, two Newton steps on the
 	// reciprocal, three on the quotient, v_div_fmas, v_div_fixup (11 instructions); the reciprocal part depends on the
-	// denominator only.  When every lane's operands are far from the exponent limits (|dkz| and the non-zero numerators within
-	// 2^+-30: then v_div_scale scales nothing, v_div_fmas is a plain fma and v_div_fixup returns its input) the same
+	// denominator only.  When every lane's operands are far from the exponent limits (|dkz| and the numerators within
+	// 2^+-40: then v_div_scale scales nothing, v_div_fmas is a plain fma and v_div_fixup returns its input) the same
 	// instructions are issued with that part shared -- 18 instead of 33, bit-identical quotients; otherwise, and always where
 	// lanes call this one by one (kShareReciprocal == false), the plain divisions.
-	bool shared = false;
-	if (kShareReciprocal)
+	if (kShareReciprocal && pt_all_in_division_range(dkz, dkx, dky))
 	{
-		const float lo = 9.31322575e-10f, hi = 1073741824.0f;  // 2^-30, 2^30
-		const float ax = fabsf(dkx), ay = fabsf(dky), az = fabsf(dkz);
-		const bool ok = az >= lo && az <= hi && ax >= lo && ax <= hi && ay >= lo && ay <= hi;
-		shared = __builtin_amdgcn_ballot_w64(!ok) == 0ull;  // wave-uniform
-	}
-	if (shared)
-	{
-		float rc = __builtin_amdgcn_rcpf(dkz);
-		float e0 = __builtin_fmaf(-dkz, rc, 1.0f);
-		rc = __builtin_fmaf(e0, rc, rc);
-		auto quotient = [&](float n) {
-			float q = n * rc;
-			float e = __builtin_fmaf(-dkz, q, n);
-			q = __builtin_fmaf(e, rc, q);
-			e = __builtin_fmaf(-dkz, q, n);
-			return __builtin_fmaf(e, rc, q);
-		};
-		r.Sx = quotient(dkx);
-		r.Sy = quotient(dky);
-		r.Sz = quotient(1.0f);
+		const PtSharedDivisor by(dkz);
+		r.Sx = by.quotient(dkx);
+		r.Sy = by.quotient(dky);
+		r.Sz = by.quotient(1.0f);
 	}
 	else
 	{
