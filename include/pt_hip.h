@@ -247,6 +247,12 @@ int pt_reset_stats(pt_ctx *ctx);
  * out_unit[i*3..] = rnd_unit_vector drawn from state out_tea[i]. */
 int pt_debug_rng(pt_ctx *ctx, uint32_t n, const uint32_t *v0, const uint32_t *v1, uint32_t n_steps,
                  uint32_t *out_tea, uint32_t *out_lcg, float *out_unit);
+/* Self-check of the arithmetic specification on the device: n pseudo-random operand sets (exponents sweeping 2^+-40 for
+ * divisions, 2^+-60 for square roots, the ends included) through the in-range instruction sequences the path kernel
+ * issues for IEEE division and sqrt, compared bit for bit with the plain operators.  mismatches[0] quotients,
+ * [1] roots, [2] reciprocal roots -- all zero or the build is not what DESIGN.md section 4 says it is; [3] = operand sets
+ * the device went through (= n). */
+int pt_debug_math(pt_ctx *ctx, uint64_t n, uint32_t seed, uint64_t mismatches[4]);
 /* Closest hits of the frame-0 primary rays (jitter = pixel centre), W*H records. */
 int pt_debug_primary_hits(pt_ctx *ctx, PtHit *hits);
 /* Closest hits for caller rays: rays = n * 6 floats (origin, direction). */

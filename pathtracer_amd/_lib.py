@@ -65,6 +65,7 @@ SYMBOLS = {
     "pt_get_stats": (_i, [_vp, C.POINTER(PtStats)]),
     "pt_reset_stats": (_i, [_vp]),
     "pt_debug_rng": (_i, [_vp, _u32, _vp, _vp, _u32, _vp, _vp, _vp]),
+    "pt_debug_math": (_i, [_vp, C.c_uint64, _u32, _vp]),
     "pt_debug_primary_hits": (_i, [_vp, _vp]),
     "pt_debug_trace": (_i, [_vp, _vp, _u32, _f, _f, _vp]),
     "pt_debug_morton": (_i, [_vp, _vp, _vp, _vp, _vp]),

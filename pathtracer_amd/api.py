@@ -326,6 +326,13 @@ class HipRaytracing:
         self._check(self._L.pt_debug_rng(self._ctx, n, _p(v0), _p(v1), n_steps, _p(tea), _p(lcg), _p(unit)))
         return tea, lcg, unit
 
+    def debugMath(self, n, seed=1):
+        """pt_debug_math: mismatch counts (quotients, roots, reciprocal roots) of the in-range IEEE forms and the number
+        of operand sets checked."""
+        bad = np.zeros(4, dtype=np.uint64)
+        self._check(self._L.pt_debug_math(self._ctx, int(n), int(seed), _p(bad)))
+        return bad
+
     def debugPrimaryHits(self) -> np.ndarray:
         hits = np.zeros(self.width * self.height, dtype=HIT_DTYPE)
         self._check(self._L.pt_debug_primary_hits(self._ctx, _p(hits)))

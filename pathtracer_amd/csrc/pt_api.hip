@@ -1194,6 +1194,29 @@ extern "C" int pt_debug_rng(pt_ctx *c, uint32_t n, const uint32_t *v0, const uin
 	return PT_OK;
 }
 
+extern "C" int pt_debug_math(pt_ctx *c, uint64_t n, uint32_t seed, uint64_t mismatches[4])
+{
+	if (!c || !mismatches) return fail(c, PT_EINVAL, "pt_debug_math: null argument");
+	if (n > (1ull << 38)) return fail(c, PT_ELIMIT, "pt_debug_math: at most 2^38 samples");
+	mismatches[0] = mismatches[1] = mismatches[2] = mismatches[3] = 0;
+	if (!n) return PT_OK;
+	PT_HIP(c, hipSetDevice(c->device));
+	unsigned long long *d = nullptr;
+	hipError_t e = hipMalloc(&d, 4 * sizeof(unsigned long long));
+	if (e == hipSuccess) e = hipMemsetAsync(d, 0, 4 * sizeof(unsigned long long), c->stream);
+	if (e == hipSuccess)
+	{
+		ptLaunchDebugMath(n, seed, d, c->stream);
+		e = hipStreamSynchronize(c->stream);
+	}
+	unsigned long long h[4] = { 0, 0, 0, 0 };
+	if (e == hipSuccess) e = hipMemcpy(h, d, sizeof(h), hipMemcpyDeviceToHost);
+	hipFree(d);
+	if (e != hipSuccess) return fail(c, PT_EHIP, "pt_debug_math: %s", hipGetErrorString(e));
+	for (int k = 0; k < 4; ++k) mismatches[k] = h[k];
+	return PT_OK;
+}
+
 extern "C" int pt_debug_primary_hits(pt_ctx *c, PtHit *hits)
 {
 	int rc = checkReady(c, true);

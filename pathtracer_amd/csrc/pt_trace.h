@@ -99,6 +99,7 @@ void ptLaunchAccumulate(const PtQueues &q, PtTile tile, uint32_t W, uint32_t spp
                         hipStream_t s);
 void ptLaunchDebugRng(uint32_t n, const uint32_t *v0, const uint32_t *v1, uint32_t nSteps, uint32_t *outTea,
                       uint32_t *outLcg, float *outUnit, hipStream_t s);
+void ptLaunchDebugMath(unsigned long long n, uint32_t seed, unsigned long long *mismatches, hipStream_t s);
 void ptLaunchPackRays(const float *rays, uint32_t n, float4 *rayO, float4 *rayD, hipStream_t s);
 void ptLaunchSetU32(uint32_t *p, uint32_t v, hipStream_t s);
 void ptLaunchBuildShadeRecords(const PtSceneDev &sc, PtShadeRec *out, hipStream_t s);

@@ -399,6 +399,54 @@ __global__ void k_debug_rng(uint32_t n, const uint32_t *v0, const uint32_t *v1, 
 	outUnit[3 * (size_t)i + 2] = u.z;
 }
 
+// In-range sqrt / division forms (pt_device_common.h) against the plain operators, on operands that sweep the exponent
+// ranges the callers' checks admit (2^+-40 for divisions, 2^+-60 for roots) with random signs and mantissas; the exact
+// ends of the ranges are visited too.  mismatches[0]: quotients, [1]: roots, [2]: reciprocal-of-root (normalize), [3]: sets checked.
+__global__ void k_debug_math(unsigned long long n, uint32_t seed, unsigned long long *mismatches)
+{
+	const unsigned long long i = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x;
+	if (threadIdx.x == 0)
+	{
+		// [3]: operand sets this launch really went through (a launch that did not run must not read as "no mismatch")
+		const unsigned long long first = (unsigned long long)blockIdx.x * blockDim.x;
+		atomicAdd(&mismatches[3], n - first < blockDim.x ? n - first : (unsigned long long)blockDim.x);
+	}
+	if (i >= n) return;
+	uint32_t st = pt_tea((uint32_t)i, seed + (uint32_t)(i >> 32));
+	auto draw = [&](int lim, uint32_t k) {
+		// exponent uniformly in [-lim, lim] (every 64th sample pinned to an end), 23 random mantissa bits, random sign
+		pt_lcg(st);
+		uint32_t r = st;
+		int e = (int)((r >> 8) % (uint32_t)(2 * lim + 1)) - lim;
+		if (((i + k) & 63u) == 0u) e = (r & 1u) ? lim : -lim;
+		pt_lcg(st);
+		uint32_t m = st & 0x7FFFFFu;
+		if (e == lim) m = 0u;  // the upper end is 2^lim itself
+		return __uint_as_float(((st >> 23) & 1u) << 31 | (uint32_t)(e + 127) << 23 | m);
+	};
+	const float d = draw(40, 0), n1 = draw(40, 1), n2 = draw(40, 2);
+	unsigned long long bad0 = 0, bad1 = 0, bad2 = 0;
+	if (pt_all_in_division_range(d, n1, n2))
+	{
+		const PtSharedDivisor by(d);
+		bad0 += __float_as_uint(by.quotient(n1)) != __float_as_uint(n1 / d);
+		bad0 += __float_as_uint(by.quotient(n2)) != __float_as_uint(n2 / d);
+		bad0 += __float_as_uint(by.quotient(1.0f)) != __float_as_uint(1.0f / d);
+	}
+	else bad0 += 1;  // the generator stays inside the range: the check must have passed
+	const float x = fabsf(draw(60, 3));
+	if (pt_all_in_range(x))
+	{
+		const float root = pt_sqrt_in_range(x);
+		bad1 += __float_as_uint(root) != __float_as_uint(__builtin_sqrtf(x));
+		bad2 += __float_as_uint(PtSharedDivisor(root).quotient(1.0f)) != __float_as_uint(1.0f / __builtin_sqrtf(x));
+	}
+	else bad1 += 1;
+	if (bad0) atomicAdd(&mismatches[0], bad0);
+	if (bad1) atomicAdd(&mismatches[1], bad1);
+	if (bad2) atomicAdd(&mismatches[2], bad2);
+}
+
 __global__ void k_pack_rays(const float *rays, uint32_t n, float4 *rayO, float4 *rayD)
 {
 	uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -489,6 +537,11 @@ void ptLaunchDebugRng(uint32_t n, const uint32_t *v0, const uint32_t *v1, uint32
                       uint32_t *outLcg, float *outUnit, hipStream_t s)
 {
 	k_debug_rng<<<divUp(n, 256), 256, 0, s>>>(n, v0, v1, nSteps, outTea, outLcg, outUnit);
+}
+
+void ptLaunchDebugMath(unsigned long long n, uint32_t seed, unsigned long long *mismatches, hipStream_t s)
+{
+	k_debug_math<<<(uint32_t)((n + 255) / 256), 256, 0, s>>>(n, seed, mismatches);
 }
 
 void ptLaunchPackRays(const float *rays, uint32_t n, float4 *rayO, float4 *rayD, hipStream_t s)

@@ -156,3 +156,12 @@ def test_srgb8_output(rt, pa, O, cornell):
     diff = np.abs(px.astype(np.int32) - want.astype(np.int32))
     assert diff.max() <= 1 and (diff > 0).mean() < 1e-3
     assert np.all(px[..., 3] == 255)
+
+
+def test_in_range_division_and_sqrt_forms_equal_the_operators(rt):
+    """the shared-reciprocal division and the unscaled sqrt the path kernel issues for in-range operands
+    are the compiler's own expansions minus identity steps -- 2^28 operand sets over the admitted exponent ranges
+    (ends included), bit for bit against `/` and sqrtf on the device."""
+    for seed in (1, 2):
+        bad = rt.debugMath(1 << 27, seed)
+        assert bad.tolist() == [0, 0, 0, 1 << 27], bad
