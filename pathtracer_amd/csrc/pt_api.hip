@@ -78,7 +78,7 @@ struct pt_ctx
 	float4 *pState = nullptr, *pRad = nullptr, *pRingO = nullptr, *pRingD = nullptr;
 	size_t pCap = 0;                        // records in pState / pRad
 	uint32_t lastLaunchFrames = 1;          // frames the most recent launch covered
-	int framesPerLaunch = 8;                // PT_FRAMES_PER_LAUNCH
+	int framesPerLaunch = 16;               // PT_FRAMES_PER_LAUNCH
 	size_t persistentBytes = 24ull << 30;   // budget for pState + pRad (PT_PERSISTENT_GB)
 
 	int profiling = 0;

@@ -12,10 +12,10 @@ tail -2 $OUT/pytest.log
 timeout -k 10 300 python -u bench.py > $OUT/bench_default_line.json 2> $OUT/bench_default.err || { tail $OUT/bench_default.err; exit 1; }
 cat $OUT/bench_default_line.json
 cd /tmp && export TMPDIR=/tmp
-timeout -k 10 200 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -- python3 $R/bench.py --steps 16 --warmup 8 --no-cpu-baseline > $OUT/bench_steps16_line.json 2> $OUT/stats.err || { tail $OUT/stats.err; exit 1; }
+timeout -k 10 200 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -- python3 $R/bench.py --steps 32 --warmup 16 --no-cpu-baseline > $OUT/bench_steps16_line.json 2> $OUT/stats.err || { tail $OUT/stats.err; exit 1; }
 cat $OUT/bench_steps16_line.json
-timeout -s KILL 90 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_fetch -- python3 $R/bench.py --steps 8 --warmup 8 --no-cpu-baseline > $OUT/pmc_fetch.log 2>&1 || { tail $OUT/pmc_fetch.log; exit 1; }
-timeout -s KILL 90 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/pmc_write -- python3 $R/bench.py --steps 8 --warmup 8 --no-cpu-baseline > $OUT/pmc_write.log 2>&1 || { tail $OUT/pmc_write.log; exit 1; }
+timeout -s KILL 90 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_fetch -- python3 $R/bench.py --steps 16 --warmup 16 --no-cpu-baseline > $OUT/pmc_fetch.log 2>&1 || { tail $OUT/pmc_fetch.log; exit 1; }
+timeout -s KILL 90 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/pmc_write -- python3 $R/bench.py --steps 16 --warmup 16 --no-cpu-baseline > $OUT/pmc_write.log 2>&1 || { tail $OUT/pmc_write.log; exit 1; }
 cd $R
 python scripts/pmc_summary.py $OUT/pmc_fetch; python scripts/pmc_summary.py $OUT/pmc_write
 find $OUT/stats -name "*kernel_stats.csv" | head -1 | xargs cat | cut -c1-120

@@ -14,6 +14,6 @@ fm, wm = sum(f) / len(f), sum(w) / len(w)
 d = {"kernel": kernel, "launches_sampled": len(f), "FETCH_SIZE_KiB_mean": fm, "WRITE_SIZE_KiB_mean": wm,
      "correction": "FETCH_SIZE x2 (gfx950 counts 128-B requests as 64 B), WRITE_SIZE x1",
      "hbm_bytes_per_launch": (2.0 * fm + wm) * 1024.0,
-     "command": "rocprofv3 --pmc FETCH_SIZE|WRITE_SIZE -- python3 bench.py --steps 8 --warmup 8 --no-cpu-baseline (mean over all launches of the kernel; one launch = 8 frames)"}
+     "command": "rocprofv3 --pmc FETCH_SIZE|WRITE_SIZE -- python3 bench.py --steps 16 --warmup 16 --no-cpu-baseline (mean over all launches of the kernel; one launch = 16 frames)"}
 json.dump(d, open(out, "w"), indent=1)
 print(d)
