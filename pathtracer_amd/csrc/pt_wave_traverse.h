@@ -186,8 +186,10 @@ __device__ __forceinline__ void pt_node_step(const PtSceneDev &sc, const PtLaneR
 			float tfz = __builtin_fmaf((float)((fqz >> (8 * c)) & 0xFFu), az, bz);
 			float t0 = fmaxf(fmaxf(tnx, tny), fmaxf(tnz, tmin));
 			float t1 = fminf(fminf(tfx, tfy), fminf(tfz, best.t));
-			bool hit = (t0 <= t1 * 1.000001f) && (ref[c] != PT_EMPTY_CHILD);
-			tn[c] = hit ? t0 : INFINITY;
+			// an empty slot is the inverted box lo = 255, hi = 0 on every axis: its entry lies 255 steps behind its exit and
+			// the test fails by itself (the stray case -- a ray so far away that 255 steps vanish in the 1e-6 slack -- pushes
+			// PT_EMPTY_CHILD, which the leaf step skips)
+			tn[c] = (t0 <= t1 * 1.000001f) ? t0 : INFINITY;
 		}
 	}
 	// sort the (entry distance, reference) pairs ascending: 5 compare-exchanges; missed children (inf) sink
