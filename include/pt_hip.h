@@ -271,6 +271,16 @@ typedef struct PtSceneData PtSceneData;
  * tinyobjloader v1.0.6 semantics (the reference's vendored external/tinyobjloader).
  * Extension: faces without normals get flat geometric normals (the reference has UB there). */
 int pt_load_obj(const char *obj_path, PtSceneData **out);
+/* The second half of PathTracer::loadModel alone (main.cpp:1122-1189), for callers that already hold what
+ * tinyobj::LoadObj (main.cpp:1117) returned: attrib_t::vertices / normals / texcoords (3, 3, 2 floats per element),
+ * the shapes' mesh.indices concatenated in shape order as tinyobj::index_t triples { vertex_index, normal_index,
+ * texcoord_index } (n_indices corners, three per triangle; -1 = absent), mesh.material_ids likewise (n_indices / 3
+ * entries, -1 = none -> the grey fallback) and the .mtl materials as Material{diffuse, emission}.  Same result as
+ * pt_load_obj on the file those arrays came from (tests/test_host_seam.py). */
+int pt_scene_from_tinyobj(const float *vertices, uint32_t n_vertices, const float *normals, uint32_t n_normals,
+                          const float *texcoords, uint32_t n_texcoords, const int32_t *indices, uint32_t n_indices,
+                          const int32_t *material_ids, const PtMaterial *materials, uint32_t n_materials,
+                          PtSceneData **out);
 void pt_scene_free(PtSceneData *s);
 uint32_t pt_scene_n_vertices(const PtSceneData *s);
 uint32_t pt_scene_n_indices(const PtSceneData *s);

@@ -296,7 +296,26 @@ def parse_obj(path: str):
 def load_model(path: str):
     """PathTracer::loadModel (main.cpp:1101-1190).  Returns dict of numpy arrays:
     vertices (n,11) f32, indices (m,) u32, materials (k,6) f32, mat_indices (m/3,) u32."""
-    obj = parse_obj(path)
+    return model_from_tinyobj(parse_obj(path))
+
+
+def tinyobj_from_arrays(vertices, normals, texcoords, indices, material_ids, materials):
+    """The dict parse_obj returns, rebuilt from flat arrays as the reference's own tinyobjloader dumped them
+    (tests/golden/ref_seam.npz: index_t triples are (vertex, normal, texcoord); one shape)."""
+    idx = np.asarray(indices, dtype=np.int64).reshape(-1, 3)
+    mats = np.asarray(materials, dtype=np.float32).reshape(-1, 6)
+    return {
+        "vertices": np.asarray(vertices, dtype=np.float32).reshape(-1),
+        "normals": np.asarray(normals, dtype=np.float32).reshape(-1),
+        "texcoords": np.asarray(texcoords, dtype=np.float32).reshape(-1),
+        "shapes": [{"indices": [(int(a), int(c), int(b)) for a, b, c in idx],  # oracle order: (v, vt, vn)
+                    "material_ids": [int(x) for x in np.asarray(material_ids).reshape(-1)]}],
+        "materials": [{"name": str(i), "diffuse": list(m[:3]), "emission": list(m[3:])} for i, m in enumerate(mats)],
+    }
+
+
+def model_from_tinyobj(obj):
+    """The loop of PathTracer::loadModel (main.cpp:1122-1189) over a parse_obj / tinyobj_from_arrays result."""
     mats = [list(m["diffuse"]) + list(m["emission"]) for m in obj["materials"]]
     mat_count = len(mats)
     mats.append([0.5, 0.5, 0.5, 0.0, 0.0, 0.0])

@@ -17,6 +17,13 @@ PT_ACCEL_BVH4 = 0
 PT_ACCEL_BRUTE_FORCE = 1
 PT_ACCEL_BVH4_PLOC = 2
 PT_ACCEL_NO_COMPACTION = 0x1000
+PT_ACCEL_LEAF_SIZE_1 = 1 << 8  # PT_ACCEL_LEAF_SIZE(1)
+
+
+def PT_ACCEL_LEAF_SIZE(n):
+    return int(n) << 8
+
+
 PT_ACCUM_MEAN = 0
 PT_ACCUM_SUM = 1
 PT_PROFILE_KERNELS = 1
@@ -71,6 +78,7 @@ SYMBOLS = {
     "pt_debug_morton": (_i, [_vp, _vp, _vp, _vp, _vp]),
     "pt_debug_read_bvh": (_i, [_vp, _vp, C.POINTER(_u32), _vp, C.POINTER(_u32)]),
     "pt_load_obj": (_i, [C.c_char_p, C.POINTER(_vp)]),
+    "pt_scene_from_tinyobj": (_i, [_vp, _u32, _vp, _u32, _vp, _u32, _vp, _u32, _vp, _vp, _u32, C.POINTER(_vp)]),
     "pt_scene_free": (None, [_vp]),
     "pt_scene_n_vertices": (_u32, [_vp]),
     "pt_scene_n_indices": (_u32, [_vp]),

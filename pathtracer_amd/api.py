@@ -15,7 +15,7 @@ from dataclasses import dataclass
 import numpy as np
 
 from . import _lib
-from ._lib import (PT_ACCEL_BRUTE_FORCE, PT_ACCEL_BVH4, PT_ACCEL_BVH4_PLOC, PT_ACCUM_MEAN, PT_ACCUM_SUM, PT_NO_HIT, PT_PROFILE_KERNELS,
+from ._lib import (PT_ACCEL_BRUTE_FORCE, PT_ACCEL_BVH4, PT_ACCEL_BVH4_PLOC, PT_ACCEL_LEAF_SIZE, PT_ACCEL_LEAF_SIZE_1, PT_ACCEL_NO_COMPACTION, PT_ACCUM_MEAN, PT_ACCUM_SUM, PT_NO_HIT, PT_PROFILE_KERNELS,
                    PT_PROFILE_TRAVERSAL, PT_PIPELINE_FUSED, PT_PIPELINE_SPLIT, PT_PIPELINE_PERSISTENT, PtStats)
 
 HIT_DTYPE = np.dtype([("t", np.float32), ("u", np.float32), ("v", np.float32), ("prim", np.uint32)])
@@ -64,6 +64,31 @@ def load_obj(path: str) -> Scene:
     rc = L.pt_load_obj(str(path).encode(), C.byref(h))
     if rc:
         raise PathTracerError(rc, L.pt_last_error(None).decode())
+    return _scene_from_handle(L, h)
+
+
+def scene_from_tinyobj(vertices, normals, texcoords, indices, material_ids, materials) -> Scene:
+    """The de-duplication half of loadModel (main.cpp:1122-1189) over arrays tinyobj::LoadObj produced
+    (pt_scene_from_tinyobj): attrib vertices / normals / texcoords, index_t triples (v, vn, vt), material ids, .mtl
+    materials (k, 6)."""
+    L = _lib.lib()
+    v = np.ascontiguousarray(vertices, dtype=np.float32).reshape(-1)
+    vn = np.ascontiguousarray(normals, dtype=np.float32).reshape(-1)
+    vt = np.ascontiguousarray(texcoords, dtype=np.float32).reshape(-1)
+    idx = np.ascontiguousarray(indices, dtype=np.int32).reshape(-1, 3)
+    mid = np.ascontiguousarray(material_ids, dtype=np.int32).reshape(-1)
+    mats = np.ascontiguousarray(materials, dtype=np.float32).reshape(-1, 6)
+    if v.size % 3 or vn.size % 3 or vt.size % 2 or idx.shape[0] % 3 or mid.size != idx.shape[0] // 3:
+        raise ValueError("scene_from_tinyobj: array sizes do not describe a triangulated tinyobj result")
+    h = C.c_void_p()
+    rc = L.pt_scene_from_tinyobj(_p(v), v.size // 3, _p(vn), vn.size // 3, _p(vt), vt.size // 2, _p(idx), idx.shape[0],
+                                 _p(mid), _p(mats), mats.shape[0], C.byref(h))
+    if rc:
+        raise PathTracerError(rc, L.pt_last_error(None).decode())
+    return _scene_from_handle(L, h)
+
+
+def _scene_from_handle(L, h) -> Scene:
     try:
         nv, ni, nm = L.pt_scene_n_vertices(h), L.pt_scene_n_indices(h), L.pt_scene_n_materials(h)
 
@@ -363,6 +388,6 @@ class HipRaytracing:
         return nodes, tris
 
 
-__all__ = ["HipRaytracing", "PathTracerError", "Scene", "load_obj", "look_at", "perspective", "inverse4",
+__all__ = ["HipRaytracing", "PathTracerError", "Scene", "load_obj", "scene_from_tinyobj", "look_at", "perspective", "inverse4",
            "reference_camera", "write_png", "write_ppm", "write_pfm", "HIT_DTYPE", "NODE_DTYPE", "TRI_DTYPE", "PT_ACCEL_BVH4", "PT_ACCEL_BVH4_PLOC", "PT_ACCEL_BRUTE_FORCE",
            "PT_ACCUM_MEAN", "PT_ACCUM_SUM", "PT_NO_HIT", "PT_PROFILE_KERNELS", "PT_PROFILE_TRAVERSAL", "PT_PIPELINE_FUSED", "PT_PIPELINE_SPLIT", "PT_PIPELINE_PERSISTENT", "PtStats"]

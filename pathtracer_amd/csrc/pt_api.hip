@@ -8,6 +8,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <new>
 #include <string>
 #include <vector>
 
@@ -78,8 +79,8 @@ struct pt_ctx
 	float4 *pState = nullptr, *pRad = nullptr, *pRingO = nullptr, *pRingD = nullptr;
 	size_t pCap = 0;                        // records in pState / pRad
 	uint32_t lastLaunchFrames = 1;          // frames the most recent launch covered
-	int framesPerLaunch = 16;               // PT_FRAMES_PER_LAUNCH
-	size_t persistentBytes = 24ull << 30;   // budget for pState + pRad (PT_PERSISTENT_GB)
+	int framesPerLaunch = 8;                // PT_FRAMES_PER_LAUNCH (16 buys +0.9 % at the headline config for 8.5 GB more)
+	size_t persistentBytes = 12ull << 30;   // budget for pState + pRad (PT_PERSISTENT_GB): 32 B per path per frame of a launch
 
 	int profiling = 0;
 	std::vector<EventPair> pending;
@@ -208,8 +209,20 @@ hipEvent_t getEvent(pt_ctx *c)
 		return e;
 	}
 	hipEvent_t e = nullptr;
-	hipEventCreate(&e);
+	if (hipEventCreate(&e) != hipSuccess) return nullptr;  // callers treat a null event as "profiling unavailable"
 	return e;
+}
+
+// Three events for one profiled launch, or none (event creation failed: that launch goes untimed).
+bool getEventTriple(pt_ctx *c, hipEvent_t &e0, hipEvent_t &e1, hipEvent_t &e2)
+{
+	e0 = getEvent(c);
+	e1 = getEvent(c);
+	e2 = getEvent(c);
+	if (e0 && e1 && e2) return true;
+	for (hipEvent_t e : { e0, e1, e2 })
+		if (e) c->freeEvents.push_back(e);
+	return false;
 }
 
 // Folds finished event pairs into the per-kernel-class totals.  Caller has synchronised the stream.
@@ -378,7 +391,7 @@ extern "C" int pt_synchronize(pt_ctx *c)
 }
 
 extern "C" int pt_upload_scene(pt_ctx *c, const PtVertex *v, uint32_t nV, const uint32_t *idx, uint32_t nIdx,
-                               const PtMaterial *m, uint32_t nM, const uint32_t *matIdx)
+                               const PtMaterial *m, uint32_t nM, const uint32_t *matIdx) try
 {
 	if (!c) return fail(nullptr, PT_EINVAL, "null context");
 	if (nIdx % 3) return fail(c, PT_EINVAL, "pt_upload_scene: n_indices (%u) is not a multiple of 3", nIdx);
@@ -426,8 +439,12 @@ extern "C" int pt_upload_scene(pt_ctx *c, const PtVertex *v, uint32_t nV, const 
 	}
 	return PT_OK;
 }
+catch (const std::bad_alloc &)
+{
+	return fail(c, PT_ENOMEM, "pt_upload_scene: out of host memory");
+}
 
-extern "C" int pt_set_texture(pt_ctx *c, const uint8_t *rgba8, uint32_t w, uint32_t h)
+extern "C" int pt_set_texture(pt_ctx *c, const uint8_t *rgba8, uint32_t w, uint32_t h) try
 {
 	if (!c) return fail(nullptr, PT_EINVAL, "null context");
 	if ((rgba8 == nullptr) != (w == 0 || h == 0)) return fail(c, PT_EINVAL, "pt_set_texture: pixels and extent must both be given or both be empty");
@@ -453,6 +470,10 @@ extern "C" int pt_set_texture(pt_ctx *c, const uint8_t *rgba8, uint32_t w, uint3
 	c->texW = w;
 	c->texH = h;
 	return PT_OK;
+}
+catch (const std::bad_alloc &)
+{
+	return fail(c, PT_ENOMEM, "pt_set_texture: out of host memory");
 }
 
 namespace
@@ -536,7 +557,7 @@ int buildTopLevel(pt_ctx *c, int builder)
 }
 }  // namespace
 
-extern "C" int pt_build_accel(pt_ctx *c, int flags)
+extern "C" int pt_build_accel(pt_ctx *c, int flags) try
 {
 	if (!c) return fail(nullptr, PT_EINVAL, "null context");
 	if (!c->haveScene) return fail(c, PT_EINVAL, "pt_build_accel: no scene uploaded");
@@ -553,15 +574,20 @@ extern "C" int pt_build_accel(pt_ctx *c, int flags)
 	PtBuildInput in = { c->dVerts, c->dIndices, c->nIdx / 3, leafMax,
 	                    mode == PT_ACCEL_BVH4_PLOC ? PT_BUILDER_PLOC : PT_BUILDER_LBVH };
 	hipEvent_t a = getEvent(c), b = getEvent(c);
-	hipEventRecord(a, c->stream);
+	const bool timed = a && b;  // without events the build is simply not timed
+	if (timed) hipEventRecord(a, c->stream);
 	hipError_t e = ptBuildBvh4(in, c->accel, c->stream);
-	hipEventRecord(b, c->stream);
-	hipEventSynchronize(b);
 	float ms = 0.0f;
-	hipEventElapsedTime(&ms, a, b);
+	if (timed)
+	{
+		hipEventRecord(b, c->stream);
+		hipEventSynchronize(b);
+		hipEventElapsedTime(&ms, a, b);
+	}
+	else hipStreamSynchronize(c->stream);
 	c->buildMs = ms;
-	c->freeEvents.push_back(a);
-	c->freeEvents.push_back(b);
+	if (a) c->freeEvents.push_back(a);
+	if (b) c->freeEvents.push_back(b);
 	if (e != hipSuccess) return fail(c, PT_EHIP, "pt_build_accel: BVH build failed: %s", hipGetErrorString(e));
 	c->blasNodes = c->accel.nNodes;
 	{
@@ -618,8 +644,12 @@ extern "C" int pt_build_accel(pt_ctx *c, int flags)
 	c->haveAccel = true;
 	return PT_OK;
 }
+catch (const std::bad_alloc &)
+{
+	return fail(c, PT_ENOMEM, "pt_build_accel: out of host memory");
+}
 
-extern "C" int pt_set_instances(pt_ctx *c, const PtInstance *inst, uint32_t n)
+extern "C" int pt_set_instances(pt_ctx *c, const PtInstance *inst, uint32_t n) try
 {
 	if (!c) return fail(nullptr, PT_EINVAL, "null context");
 	if (n && !inst) return fail(c, PT_EINVAL, "pt_set_instances: null array");
@@ -656,6 +686,10 @@ extern "C" int pt_set_instances(pt_ctx *c, const PtInstance *inst, uint32_t n)
 	c->haveAccel = false;  // the top-level structure must be rebuilt: pt_build_accel
 	c->frame = -1;
 	return PT_OK;
+}
+catch (const std::bad_alloc &)
+{
+	return fail(c, PT_ENOMEM, "pt_set_instances: out of host memory");
 }
 
 extern "C" int pt_resize(pt_ctx *c, uint32_t W, uint32_t H)
@@ -777,8 +811,10 @@ int ensureLcgSkip(pt_ctx *c)
 }
 
 // Buffers of the persistent pipeline: per-path state and radiance for every frame of a launch, wave-private rings.
-int ensurePersistent(pt_ctx *c, size_t records)
+// outOfMemory: set when the state/radiance pair does not fit -- the caller retries with fewer frames per launch.
+int ensurePersistent(pt_ctx *c, size_t records, bool *outOfMemory)
 {
+	*outOfMemory = false;
 	if (records > c->pCap)
 	{
 		PT_HIP(c, hipStreamSynchronize(c->stream));
@@ -786,8 +822,17 @@ int ensurePersistent(pt_ctx *c, size_t records)
 		hipFree(c->pRad);
 		c->pState = c->pRad = nullptr;
 		c->pCap = 0;
-		PT_HIP(c, hipMalloc(&c->pState, records * sizeof(float4)));
-		PT_HIP(c, hipMalloc(&c->pRad, records * sizeof(float4)));
+		hipError_t e = hipMalloc(&c->pState, records * sizeof(float4));
+		if (e == hipSuccess) e = hipMalloc(&c->pRad, records * sizeof(float4));
+		if (e != hipSuccess)
+		{
+			hipFree(c->pState);
+			c->pState = c->pRad = nullptr;
+			(void)hipGetLastError();
+			*outOfMemory = (e == hipErrorOutOfMemory);
+			return fail(c, e == hipErrorOutOfMemory ? PT_ENOMEM : PT_EHIP, "pt_render_frame: %zu bytes of path state: %s",
+			            records * 2 * sizeof(float4), hipGetErrorString(e));
+		}
 		c->pCap = records;
 	}
 	if (!c->pRingO)
@@ -808,7 +853,17 @@ int renderPersistent(pt_ctx *c, int n)
 	// frames per launch: path ids q = item * 64 + lane stay below 2^32, state + radiance stay below the memory budget
 	size_t perLaunch = (size_t)c->framesPerLaunch;
 	if (perLaunch * nPadded > 0xFFFFFF00ull) perLaunch = 0xFFFFFF00ull / nPadded;
-	if (perLaunch * nPadded * 32 > c->persistentBytes) perLaunch = c->persistentBytes / (nPadded * 32);
+	size_t budget = c->persistentBytes;
+	{
+		// never plan for more than half of what the device has left (plus what these buffers already hold)
+		size_t freeB = 0, totalB = 0;
+		if (hipMemGetInfo(&freeB, &totalB) == hipSuccess)
+		{
+			const size_t room = (freeB + c->pCap * 32) / 2;
+			if (room < budget) budget = room;
+		}
+	}
+	if (perLaunch * nPadded * 32 > budget) perLaunch = budget / (nPadded * 32);
 	if (perLaunch < 1) perLaunch = 1;
 	if (nPadded > 0xFFFFFF00ull) return fail(c, PT_EINVAL, "pt_render_frame: %zu paths per frame exceed 2^32", nPadded);
 	int rc = ensureLcgSkip(c);
@@ -824,10 +879,17 @@ int renderPersistent(pt_ctx *c, int n)
 	unsigned long long *trav = (c->profiling & PT_PROFILE_TRAVERSAL) ? c->dStats + 2 : nullptr;
 	while (n > 0)
 	{
-		const uint32_t batch = (uint32_t)((size_t)n < perLaunch ? (size_t)n : perLaunch);
+		uint32_t batch = (uint32_t)((size_t)n < perLaunch ? (size_t)n : perLaunch);
 		// a multi-frame call sizes the buffers for full launches at once, so that a later, longer call (warm-up of 4 frames,
 		// then 64) does not reallocate 8 GB in the middle of a render; frame-by-frame callers keep a one-frame buffer
-		rc = ensurePersistent(c, nPadded * (n > 1 ? perLaunch : (size_t)batch));
+		// (a second context on the GPU, or a 4K frame, may leave less room than the budget: halve and try again)
+		bool oom = false;
+		rc = ensurePersistent(c, nPadded * (n > 1 ? perLaunch : (size_t)batch), &oom);
+		if (rc && oom && perLaunch > 1 && n > 1)
+		{
+			perLaunch = (perLaunch + 1) / 2;
+			continue;
+		}
 		if (rc) return rc;
 		const uint32_t frame0 = (uint32_t)(c->frame + 1);
 		const uint32_t gframe0 = c->firstFrame + frame0 * c->frameStride;
@@ -838,10 +900,8 @@ int renderPersistent(pt_ctx *c, int n)
 		hipEvent_t e0 = nullptr, e1 = nullptr, e2 = nullptr;
 		if (c->profiling & PT_PROFILE_KERNELS)
 		{
-			e0 = getEvent(c);
-			e1 = getEvent(c);
-			e2 = getEvent(c);
-			hipEventRecord(e0, s);
+			if (!getEventTriple(c, e0, e1, e2)) e0 = e1 = e2 = nullptr;
+			else hipEventRecord(e0, s);
 		}
 		PtPathsArgs pa;
 		pa.sc = sc;
@@ -910,10 +970,8 @@ int renderClassic(pt_ctx *c)
 		hipEvent_t e0 = nullptr, e1 = nullptr, e2 = nullptr;
 		if (c->profiling & PT_PROFILE_KERNELS)
 		{
-			e0 = getEvent(c);
-			e1 = getEvent(c);
-			e2 = getEvent(c);
-			hipEventRecord(e0, s);
+			if (!getEventTriple(c, e0, e1, e2)) e0 = e1 = e2 = nullptr;
+			else hipEventRecord(e0, s);
 		}
 		if (fused)
 		{
@@ -947,7 +1005,7 @@ int renderClassic(pt_ctx *c)
 
 // VulkanRaytracing::raytrace, n times: the frame counter always advances (updateFrame); frames at or beyond
 // max_frames are no-ops ("Max frames reached", VulkanRaytracing.cpp:877-886).
-extern "C" int pt_render_frames(pt_ctx *c, int n)
+extern "C" int pt_render_frames(pt_ctx *c, int n) try
 {
 	int rc = checkReady(c, true);
 	if (rc) return rc;
@@ -975,6 +1033,10 @@ extern "C" int pt_render_frames(pt_ctx *c, int n)
 	}
 	c->frame += (int)(n - active);
 	return PT_OK;
+}
+catch (const std::bad_alloc &)
+{
+	return fail(c, PT_ENOMEM, "pt_render_frames: out of host memory");
 }
 
 extern "C" int pt_render_frame(pt_ctx *c) { return pt_render_frames(c, 1); }
@@ -1029,75 +1091,137 @@ namespace
 {
 struct CheckpointHeader
 {
-	char magic[8];  // "PTCKPT01"
+	char magic[8];  // "PTCKPT02" ("PTCKPT01": the same without the tile, read as the whole image)
 	uint32_t W, H;
 	int32_t frame, accumMode;
 	uint32_t firstFrame, frameStride, seed;
 	int32_t spp, maxDepth, maxFrames;
 	float tmin, tmax;
+	uint32_t tile[4];  // x0, y0, w, h of pt_set_tile; w = 0: the whole image
 };
+constexpr size_t kCheckpointHeaderV1 = offsetof(CheckpointHeader, tile);
 }  // namespace
 
 extern "C" int pt_save_checkpoint(pt_ctx *c, const char *path)
 {
 	if (!c || !path) return fail(c, PT_EINVAL, "pt_save_checkpoint: null argument");
 	if (!c->image) return fail(c, PT_EINVAL, "pt_save_checkpoint: no image (pt_resize)");
-	std::vector<float> px(4 * (size_t)c->W * c->H);
-	int rc = pt_read_image(c, px.data());
-	if (rc) return rc;
-	CheckpointHeader h;
-	memcpy(h.magic, "PTCKPT01", 8);
-	h.W = c->W;
-	h.H = c->H;
-	h.frame = c->frame;
-	h.accumMode = c->accumMode;
-	h.firstFrame = c->firstFrame;
-	h.frameStride = c->frameStride;
-	h.seed = c->seed;
-	h.spp = c->spp;
-	h.maxDepth = c->maxDepth;
-	h.maxFrames = c->maxFrames;
-	h.tmin = c->tmin;
-	h.tmax = c->tmax;
-	FILE *f = fopen(path, "wb");
-	if (!f) return fail(c, PT_EIO, "pt_save_checkpoint: cannot open %s", path);
-	bool ok = fwrite(&h, sizeof(h), 1, f) == 1 && fwrite(px.data(), sizeof(float), px.size(), f) == px.size();
-	ok = (fclose(f) == 0) && ok;
-	return ok ? PT_OK : fail(c, PT_EIO, "pt_save_checkpoint: write to %s failed", path);
+	try
+	{
+		std::vector<float> px(4 * (size_t)c->W * c->H);
+		int rc = pt_read_image(c, px.data());
+		if (rc) return rc;
+		CheckpointHeader h;
+		memcpy(h.magic, "PTCKPT02", 8);
+		h.W = c->W;
+		h.H = c->H;
+		h.frame = c->frame;
+		h.accumMode = c->accumMode;
+		h.firstFrame = c->firstFrame;
+		h.frameStride = c->frameStride;
+		h.seed = c->seed;
+		h.spp = c->spp;
+		h.maxDepth = c->maxDepth;
+		h.maxFrames = c->maxFrames;
+		h.tmin = c->tmin;
+		h.tmax = c->tmax;
+		h.tile[0] = c->tile.x0;
+		h.tile[1] = c->tile.y0;
+		h.tile[2] = c->tile.w;
+		h.tile[3] = c->tile.h;
+		FILE *f = fopen(path, "wb");
+		if (!f) return fail(c, PT_EIO, "pt_save_checkpoint: cannot open %s", path);
+		bool ok = fwrite(&h, sizeof(h), 1, f) == 1 && fwrite(px.data(), sizeof(float), px.size(), f) == px.size();
+		ok = (fclose(f) == 0) && ok;
+		return ok ? PT_OK : fail(c, PT_EIO, "pt_save_checkpoint: write to %s failed", path);
+	}
+	catch (const std::bad_alloc &)
+	{
+		return fail(c, PT_ENOMEM, "pt_save_checkpoint: out of host memory");
+	}
 }
 
+// Everything is read and validated BEFORE the context is touched: a file that is refused leaves the context as it was.
 extern "C" int pt_load_checkpoint(pt_ctx *c, const char *path)
 {
 	if (!c || !path) return fail(c, PT_EINVAL, "pt_load_checkpoint: null argument");
 	FILE *f = fopen(path, "rb");
 	if (!f) return fail(c, PT_EIO, "pt_load_checkpoint: cannot open %s", path);
 	CheckpointHeader h;
-	if (fread(&h, sizeof(h), 1, f) != 1 || memcmp(h.magic, "PTCKPT01", 8) != 0 || !h.W || !h.H ||
-	    (uint64_t)h.W * h.H > 0x3FFFFFFFull)
+	memset(&h, 0, sizeof(h));
+	size_t headerBytes = 0;
+	if (fread(&h, kCheckpointHeaderV1, 1, f) == 1)
+	{
+		if (memcmp(h.magic, "PTCKPT01", 8) == 0) headerBytes = kCheckpointHeaderV1;
+		else if (memcmp(h.magic, "PTCKPT02", 8) == 0 && fread(h.tile, sizeof(h.tile), 1, f) == 1) headerBytes = sizeof(h);
+	}
+	if (!headerBytes || !h.W || !h.H || (uint64_t)h.W * h.H > 0x3FFFFFFFull)
 	{
 		fclose(f);
 		return fail(c, PT_EINVAL, "pt_load_checkpoint: %s is not a checkpoint", path);
 	}
-	std::vector<float> px(4 * (size_t)h.W * h.H);
+	const char *bad = nullptr;
+	if (h.accumMode != PT_ACCUM_MEAN && h.accumMode != PT_ACCUM_SUM) bad = "bad accumulation mode";
+	else if (!h.frameStride) bad = "frame stride 0";
+	else if (h.frame < -1 || h.frame > 0x7FFFFFFF - 4096) bad = "frame index out of range";
+	else if (h.spp < 1 || h.maxDepth < 1 || h.maxDepth > PT_MAX_DEPTH) bad = "sampling parameters out of range";
+	else if (!(h.tmin >= 0.0f) || !(h.tmax > h.tmin)) bad = "ray interval out of range";
+	else if ((uint64_t)h.W * h.H * (uint64_t)h.spp > 0xFFFFFFF0ull) bad = "W*H*spp_per_frame exceeds 2^32 path ids";
+	else if (h.tile[2] || h.tile[3])
+	{
+		if (!h.tile[2] || !h.tile[3] || (uint64_t)h.tile[0] + h.tile[2] > h.W || (uint64_t)h.tile[1] + h.tile[3] > h.H)
+			bad = "tile does not fit the image";
+	}
+	// the payload must be there before anything of its size is allocated
+	const uint64_t payload = 16ull * h.W * h.H;
+	if (!bad)
+	{
+		long here = ftell(f);
+		if (here < 0 || fseek(f, 0, SEEK_END) != 0) bad = "cannot seek";
+		else
+		{
+			long end = ftell(f);
+			if (end < 0 || (uint64_t)(end - here) != payload) bad = "truncated or oversized payload";
+			else if (fseek(f, here, SEEK_SET) != 0) bad = "cannot seek";
+		}
+	}
+	if (bad)
+	{
+		fclose(f);
+		return fail(c, PT_EINVAL, "pt_load_checkpoint: %s: %s", path, bad);
+	}
+	std::vector<float> px;
+	try
+	{
+		px.resize(4 * (size_t)h.W * h.H);
+	}
+	catch (const std::bad_alloc &)
+	{
+		fclose(f);
+		return fail(c, PT_ENOMEM, "pt_load_checkpoint: out of host memory for %u x %u", h.W, h.H);
+	}
 	size_t got = fread(px.data(), sizeof(float), px.size(), f);
 	fclose(f);
 	if (got != px.size()) return fail(c, PT_EINVAL, "pt_load_checkpoint: %s is truncated", path);
-	if (h.accumMode != PT_ACCUM_MEAN && h.accumMode != PT_ACCUM_SUM) return fail(c, PT_EINVAL, "pt_load_checkpoint: bad accumulation mode");
-	int rc = pt_set_params(c, h.spp, h.maxDepth, h.tmin, h.tmax, h.seed, h.maxFrames);
+	// the image first (the only step that can still fail: device memory), then the scalars
+	int rc = pt_resize(c, h.W, h.H);  // also drops frames still in flight; resets the tile
 	if (rc) return rc;
-	if (!h.frameStride) return fail(c, PT_EINVAL, "pt_load_checkpoint: frame stride 0");
-	rc = pt_resize(c, h.W, h.H);  // also drops frames still in flight
-	if (rc) return rc;
+	PT_HIP(c, hipMemcpy(c->image, px.data(), sizeof(float) * px.size(), hipMemcpyHostToDevice));
+	c->spp = h.spp;
+	c->maxDepth = h.maxDepth;
+	c->tmin = h.tmin;
+	c->tmax = h.tmax;
+	c->seed = h.seed;
+	c->maxFrames = h.maxFrames;
 	c->firstFrame = h.firstFrame;
 	c->frameStride = h.frameStride;
 	c->accumMode = h.accumMode;
-	PT_HIP(c, hipSetDevice(c->device));
-	PT_HIP(c, hipMemcpy(c->image, px.data(), sizeof(float) * px.size(), hipMemcpyHostToDevice));
+	c->tile = PtTile{ h.tile[0], h.tile[1], h.tile[2], h.tile[3] };
 	c->frame = h.frame;  // the next pt_render_frame renders frame + 1, as if the run had never stopped
 	return PT_OK;
 }
 
-extern "C" int pt_read_image_srgb8(pt_ctx *c, uint8_t *rgba8)
+extern "C" int pt_read_image_srgb8(pt_ctx *c, uint8_t *rgba8) try
 {
 	if (!c || !rgba8) return fail(c, PT_EINVAL, "pt_read_image_srgb8: null argument");
 	if (!c->image) return fail(c, PT_EINVAL, "pt_read_image_srgb8: no image (pt_resize)");
@@ -1111,6 +1235,10 @@ extern "C" int pt_read_image_srgb8(pt_ctx *c, uint8_t *rgba8)
 	hipFree(tmp);
 	if (e != hipSuccess) return fail(c, PT_EHIP, "pt_read_image_srgb8: %s", hipGetErrorString(e));
 	return PT_OK;
+}
+catch (const std::bad_alloc &)
+{
+	return fail(c, PT_ENOMEM, "pt_read_image_srgb8: out of host memory");
 }
 
 extern "C" int pt_set_profiling(pt_ctx *c, int flags)

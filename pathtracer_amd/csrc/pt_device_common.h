@@ -351,7 +351,10 @@ __device__ __forceinline__ PtHit pt_finish_hit(const PtBest &b, float tmax)
 // 64-byte quantised BVH4 node: one 64 B-aligned record = four 16-byte loads per lane.
 //   child box c, axis a:  lo = origin[a] + qlo[a][c] * scale[a],  hi likewise with qhi; scale[a] is a power of two
 //   stored as a float (no decode instructions in the traversal).
-//   An empty child slot has qlo = 255, qhi = 0 on every axis (never intersected).
+//   An empty child slot has qlo = 255, qhi = 0 on every axis and child = PT_EMPTY_CHILD: an inverted box, which fails the
+//   interval test of the wave kernels by itself -- except for a ray so far away that the node's whole extent vanishes in the
+//   test's 1e-6 relative slack; such a ray pushes PT_EMPTY_CHILD, which the leaf step pops without touching memory
+//   (tests/test_gpu_edge.py::test_tiny_far_geometry_matches_brute_force).  The split kernel tests the reference instead.
 //   child[c]: bit 31 = leaf.  inner: node index.  leaf: bits 30..28 = triangle count - 1,
 //   bits 27..0 = first triangle in the leaf-ordered triangle array.
 struct __attribute__((aligned(64))) PtNode4

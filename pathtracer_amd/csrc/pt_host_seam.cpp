@@ -17,12 +17,14 @@
 // tests/test_host_seam.py pins all of this against the real library (tests/golden/ref_seam.npz).
 #include "../../include/pt_hip.h"
 
+#include <algorithm>
 #include <cmath>
 #include <cstdlib>
 #include <cstdio>
 #include <cstring>
 #include <fstream>
 #include <map>
+#include <new>
 #include <sstream>
 #include <string>
 #include <unordered_map>
@@ -320,7 +322,107 @@ VertexKey makeKey(const PtVertex &v)
 }
 }  // namespace
 
-extern "C" int pt_load_obj(const char *obj_path, PtSceneData **out)
+namespace
+{
+// PathTracer::loadModel's loop over what tinyobj::LoadObj returned (main.cpp:1122-1189): materials -> Material{diffuse,
+// emission} + the appended grey(0.5) fallback, per-face material indices (-1 -> fallback), first-occurrence vertex
+// de-duplication, white vertex colour, V flipped.  corners = tinyobj::index_t per face corner, three per triangle, all
+// shapes concatenated in shape order.  Extension: a corner without a normal gets its triangle's flat geometric normal.
+int loadModelFromArrays(const char *who, const std::vector<float> &v, const std::vector<float> &vn, const std::vector<float> &vt,
+                        const std::vector<Corner> &corners, const std::vector<int> &materialIds,
+                        const std::vector<PtMaterial> &mtlMaterials, PtSceneData *sd)
+{
+	sd->materials = mtlMaterials;
+	const uint32_t matCount = (uint32_t)sd->materials.size();
+	PtMaterial grey = { { 0.5f, 0.5f, 0.5f }, { 0.0f, 0.0f, 0.0f } };
+	sd->materials.push_back(grey);
+
+	std::unordered_map<VertexKey, uint32_t, VertexKeyHash> unique;
+	for (int id : materialIds)
+	{
+		if (id < -1 || (id >= 0 && (uint32_t)id >= matCount))
+		{
+			g_seamError = std::string(who) + ": material id out of range";
+			return PT_EINVAL;
+		}
+		sd->matIndices.push_back(id == -1 ? matCount : (uint32_t)id);
+	}
+	for (size_t tri = 0; tri + 2 < corners.size(); tri += 3)
+	{
+		float flat[3] = { 0, 0, 1 };
+		bool haveFlat = false;
+		for (int j = 0; j < 3; ++j)
+		{
+			const Corner &c = corners[tri + j];
+			if (c.v < 0 || (size_t)(3 * (size_t)c.v + 2) >= v.size())
+			{
+				g_seamError = std::string(who) + ": face references a vertex that does not exist";
+				return PT_EIO;
+			}
+		}
+		for (int j = 0; j < 3; ++j)
+		{
+			const Corner &c = corners[tri + j];
+			PtVertex vert;
+			for (int k = 0; k < 3; ++k) vert.pos[k] = v[3 * (size_t)c.v + k];
+			if (c.vn >= 0 && (size_t)(3 * (size_t)c.vn + 2) < vn.size())
+			{
+				for (int k = 0; k < 3; ++k) vert.normal[k] = vn[3 * (size_t)c.vn + k];
+			}
+			else
+			{
+				// Extension (reference: out-of-bounds read, main.cpp:1162-1164): flat normal.
+				if (!haveFlat)
+				{
+					const float *p0 = &v[3 * (size_t)corners[tri].v], *p1 = &v[3 * (size_t)corners[tri + 1].v],
+					            *p2 = &v[3 * (size_t)corners[tri + 2].v];
+					float e1[3] = { p1[0] - p0[0], p1[1] - p0[1], p1[2] - p0[2] };
+					float e2[3] = { p2[0] - p0[0], p2[1] - p0[1], p2[2] - p0[2] };
+					float cx = e1[1] * e2[2] - e2[1] * e1[2];
+					float cy = e1[2] * e2[0] - e2[2] * e1[0];
+					float cz = e1[0] * e2[1] - e2[0] * e1[1];
+					float l2 = (cx * cx + cy * cy) + cz * cz;
+					if (l2 > 0.0f)
+					{
+						float inv = 1.0f / std::sqrt(l2);
+						flat[0] = cx * inv;
+						flat[1] = cy * inv;
+						flat[2] = cz * inv;
+					}
+					haveFlat = true;
+				}
+				for (int k = 0; k < 3; ++k) vert.normal[k] = flat[k];
+			}
+			if (c.vt >= 0 && (size_t)(2 * (size_t)c.vt + 1) < vt.size())
+			{
+				vert.texCoord[0] = vt[2 * (size_t)c.vt];
+				vert.texCoord[1] = 1.0f - vt[2 * (size_t)c.vt + 1];
+			}
+			else
+			{
+				vert.texCoord[0] = 0.0f;
+				vert.texCoord[1] = 0.0f;
+			}
+			vert.color[0] = vert.color[1] = vert.color[2] = 1.0f;
+			VertexKey key = makeKey(vert);
+			auto it = unique.find(key);
+			uint32_t id;
+			if (it == unique.end())
+			{
+				id = (uint32_t)sd->vertices.size();
+				unique.emplace(key, id);
+				sd->vertices.push_back(vert);
+			}
+			else
+				id = it->second;
+			sd->indices.push_back(id);
+		}
+	}
+	return PT_OK;
+}
+}  // namespace
+
+extern "C" int pt_load_obj(const char *obj_path, PtSceneData **out) try
 {
 	if (!obj_path || !out)
 	{
@@ -431,8 +533,7 @@ extern "C" int pt_load_obj(const char *obj_path, PtSceneData **out)
 	if (flushFaces(shape, pending, material) || !shape.corners.empty()) shapes.push_back(shape);
 
 	// ---- PathTracer::loadModel (main.cpp:1122-1189) ----
-	PtSceneData *sd = new PtSceneData();
-	sd->warnings = warnings;
+	std::vector<PtMaterial> mats;
 	for (const MtlEntry &m : mtl)
 	{
 		PtMaterial pm;
@@ -441,87 +542,69 @@ extern "C" int pt_load_obj(const char *obj_path, PtSceneData **out)
 			pm.diffuse[k] = m.kd[k];
 			pm.emission[k] = m.ke[k];
 		}
-		sd->materials.push_back(pm);
+		mats.push_back(pm);
 	}
-	const uint32_t matCount = (uint32_t)sd->materials.size();
-	PtMaterial grey = { { 0.5f, 0.5f, 0.5f }, { 0.0f, 0.0f, 0.0f } };
-	sd->materials.push_back(grey);
-
-	std::unordered_map<VertexKey, uint32_t, VertexKeyHash> unique;
+	std::vector<Corner> corners;
+	std::vector<int> materialIds;
 	for (const Shape &s : shapes)
 	{
-		for (int id : s.materialIds) sd->matIndices.push_back(id == -1 ? matCount : (uint32_t)id);
-		for (size_t tri = 0; tri + 2 < s.corners.size(); tri += 3)
-		{
-			float flat[3] = { 0, 0, 1 };
-			bool haveFlat = false;
-			for (int j = 0; j < 3; ++j)
-			{
-				const Corner &c = s.corners[tri + j];
-				if (c.v < 0 || (size_t)(3 * c.v + 2) >= v.size())
-				{
-					g_seamError = "pt_load_obj: face references a vertex that does not exist";
-					delete sd;
-					return PT_EIO;
-				}
-				PtVertex vert;
-				for (int k = 0; k < 3; ++k) vert.pos[k] = v[3 * c.v + k];
-				if (c.vn >= 0 && (size_t)(3 * c.vn + 2) < vn.size())
-				{
-					for (int k = 0; k < 3; ++k) vert.normal[k] = vn[3 * c.vn + k];
-				}
-				else
-				{
-					// Extension (reference: out-of-bounds read, main.cpp:1162-1164): flat normal.
-					if (!haveFlat)
-					{
-						const float *p0 = &v[3 * s.corners[tri].v], *p1 = &v[3 * s.corners[tri + 1].v],
-						            *p2 = &v[3 * s.corners[tri + 2].v];
-						float e1[3] = { p1[0] - p0[0], p1[1] - p0[1], p1[2] - p0[2] };
-						float e2[3] = { p2[0] - p0[0], p2[1] - p0[1], p2[2] - p0[2] };
-						float cx = e1[1] * e2[2] - e2[1] * e1[2];
-						float cy = e1[2] * e2[0] - e2[2] * e1[0];
-						float cz = e1[0] * e2[1] - e2[0] * e1[1];
-						float l2 = (cx * cx + cy * cy) + cz * cz;
-						if (l2 > 0.0f)
-						{
-							float inv = 1.0f / std::sqrt(l2);
-							flat[0] = cx * inv;
-							flat[1] = cy * inv;
-							flat[2] = cz * inv;
-						}
-						haveFlat = true;
-					}
-					for (int k = 0; k < 3; ++k) vert.normal[k] = flat[k];
-				}
-				if (c.vt >= 0 && (size_t)(2 * c.vt + 1) < vt.size())
-				{
-					vert.texCoord[0] = vt[2 * c.vt];
-					vert.texCoord[1] = 1.0f - vt[2 * c.vt + 1];
-				}
-				else
-				{
-					vert.texCoord[0] = 0.0f;
-					vert.texCoord[1] = 0.0f;
-				}
-				vert.color[0] = vert.color[1] = vert.color[2] = 1.0f;
-				VertexKey key = makeKey(vert);
-				auto it = unique.find(key);
-				uint32_t id;
-				if (it == unique.end())
-				{
-					id = (uint32_t)sd->vertices.size();
-					unique.emplace(key, id);
-					sd->vertices.push_back(vert);
-				}
-				else
-					id = it->second;
-				sd->indices.push_back(id);
-			}
-		}
+		corners.insert(corners.end(), s.corners.begin(), s.corners.end());
+		materialIds.insert(materialIds.end(), s.materialIds.begin(), s.materialIds.end());
+	}
+	PtSceneData *sd = new PtSceneData();
+	sd->warnings = warnings;
+	int rc = loadModelFromArrays("pt_load_obj", v, vn, vt, corners, materialIds, mats, sd);
+	if (rc)
+	{
+		delete sd;
+		return rc;
 	}
 	*out = sd;
 	return PT_OK;
+}
+catch (const std::bad_alloc &)
+{
+	g_seamError = "pt_load_obj: out of host memory";
+	return PT_ENOMEM;
+}
+
+extern "C" int pt_scene_from_tinyobj(const float *vertices, uint32_t n_vertices, const float *normals, uint32_t n_normals,
+                                    const float *texcoords, uint32_t n_texcoords, const int32_t *indices,
+                                    uint32_t n_indices, const int32_t *material_ids, const PtMaterial *materials,
+                                    uint32_t n_materials, PtSceneData **out) try
+{
+	if (!out || (n_vertices && !vertices) || (n_normals && !normals) || (n_texcoords && !texcoords) || (n_indices && !indices) ||
+	    (n_indices && !material_ids) || (n_materials && !materials) || n_indices % 3)
+	{
+		g_seamError = "pt_scene_from_tinyobj: bad argument";
+		return PT_EINVAL;
+	}
+	std::vector<float> v(vertices, vertices + 3 * (size_t)n_vertices), vn(normals, normals + 3 * (size_t)n_normals),
+	    vt(texcoords, texcoords + 2 * (size_t)n_texcoords);
+	std::vector<Corner> corners(n_indices);
+	for (uint32_t i = 0; i < n_indices; ++i)
+	{
+		// tinyobj::index_t { vertex_index, normal_index, texcoord_index }
+		corners[i].v = indices[3 * (size_t)i];
+		corners[i].vn = indices[3 * (size_t)i + 1];
+		corners[i].vt = indices[3 * (size_t)i + 2];
+	}
+	std::vector<int> ids(material_ids, material_ids + n_indices / 3);
+	std::vector<PtMaterial> mats(materials, materials + n_materials);
+	PtSceneData *sd = new PtSceneData();
+	int rc = loadModelFromArrays("pt_scene_from_tinyobj", v, vn, vt, corners, ids, mats, sd);
+	if (rc)
+	{
+		delete sd;
+		return rc;
+	}
+	*out = sd;
+	return PT_OK;
+}
+catch (const std::bad_alloc &)
+{
+	g_seamError = "pt_scene_from_tinyobj: out of host memory";
+	return PT_ENOMEM;
 }
 
 extern "C" void pt_scene_free(PtSceneData *s) { delete s; }
@@ -628,7 +711,7 @@ extern "C" void pt_reference_camera(uint32_t width, uint32_t height, float view[
 }
 
 // ---------------------------------------------------------------------- image writers ----
-extern "C" int pt_write_pfm(const char *path, const float *rgba, uint32_t w, uint32_t h)
+extern "C" int pt_write_pfm(const char *path, const float *rgba, uint32_t w, uint32_t h) try
 {
 	FILE *f = fopen(path, "wb");
 	if (!f)
@@ -648,8 +731,13 @@ extern "C" int pt_write_pfm(const char *path, const float *rgba, uint32_t w, uin
 	fclose(f);
 	return PT_OK;
 }
+catch (const std::bad_alloc &)
+{
+	g_seamError = "pt_write_pfm: out of host memory";
+	return PT_ENOMEM;
+}
 
-extern "C" int pt_write_ppm(const char *path, const uint8_t *rgba8, uint32_t w, uint32_t h)
+extern "C" int pt_write_ppm(const char *path, const uint8_t *rgba8, uint32_t w, uint32_t h) try
 {
 	FILE *f = fopen(path, "wb");
 	if (!f)
@@ -668,27 +756,35 @@ extern "C" int pt_write_ppm(const char *path, const uint8_t *rgba8, uint32_t w, 
 	fclose(f);
 	return PT_OK;
 }
+catch (const std::bad_alloc &)
+{
+	g_seamError = "pt_write_ppm: out of host memory";
+	return PT_ENOMEM;
+}
 
 // ---------------------------------------------------------------------------- PNG ----
 // 8-bit RGBA PNG with stored (uncompressed) deflate blocks: no dependency, bit-exact round trip.  The
 // reference only presents to a window (main.cpp:1414-1432); SURVEY.md 8(f) row 1 asks for a writer.
 namespace
 {
-uint32_t crc32Update(uint32_t crc, const uint8_t *p, size_t n)
+struct Crc32Table
 {
-	static uint32_t table[256];
-	static bool init = false;
-	if (!init)
+	uint32_t t[256];
+	Crc32Table()
 	{
 		for (uint32_t i = 0; i < 256; ++i)
 		{
 			uint32_t c = i;
 			for (int k = 0; k < 8; ++k) c = (c & 1u) ? 0xEDB88320u ^ (c >> 1) : c >> 1;
-			table[i] = c;
+			t[i] = c;
 		}
-		init = true;
 	}
-	for (size_t i = 0; i < n; ++i) crc = table[(crc ^ p[i]) & 0xFFu] ^ (crc >> 8);
+};
+
+uint32_t crc32Update(uint32_t crc, const uint8_t *p, size_t n)
+{
+	static const Crc32Table table;  // initialised once, thread-safe (C++11 function-local static)
+	for (size_t i = 0; i < n; ++i) crc = table.t[(crc ^ p[i]) & 0xFFu] ^ (crc >> 8);
 	return crc;
 }
 
@@ -715,7 +811,7 @@ bool writeChunk(FILE *f, const char type[4], const std::vector<uint8_t> &data)
 }
 }  // namespace
 
-extern "C" int pt_write_png(const char *path, const uint8_t *rgba8, uint32_t w, uint32_t h)
+extern "C" int pt_write_png(const char *path, const uint8_t *rgba8, uint32_t w, uint32_t h) try
 {
 	if (!path || !rgba8 || w == 0 || h == 0 || (uint64_t)w * h * 4 + h > 0x7FFFFFF0ull)
 	{
@@ -784,6 +880,11 @@ extern "C" int pt_write_png(const char *path, const uint8_t *rgba8, uint32_t w, 
 		return PT_EIO;
 	}
 	return PT_OK;
+}
+catch (const std::bad_alloc &)
+{
+	g_seamError = "pt_write_png: out of host memory";
+	return PT_ENOMEM;
 }
 
 // ------------------------------------------------------------------------------ PNG reader ----
@@ -961,7 +1062,7 @@ uint32_t get32be(const uint8_t *p) { return ((uint32_t)p[0] << 24) | ((uint32_t)
 
 extern "C" void pt_free(void *p) { free(p); }
 
-extern "C" int pt_load_png(const char *path, uint8_t **outRgba, uint32_t *outW, uint32_t *outH)
+extern "C" int pt_load_png(const char *path, uint8_t **outRgba, uint32_t *outW, uint32_t *outH) try
 {
 	if (!path || !outRgba || !outW || !outH)
 	{
@@ -1020,7 +1121,8 @@ extern "C" int pt_load_png(const char *path, uint8_t **outRgba, uint32_t *outW, 
 	const int ch = colour == 0 ? 1 : colour == 2 ? 3 : colour == 3 ? 1 : colour == 4 ? 2 : 4;
 	const size_t stride = (size_t)w * ch, rawLen = (stride + 1) * h;
 	std::vector<uint8_t> raw;
-	raw.reserve(rawLen);
+	// deflate expands at most 1032 : 1, so a small file that merely CLAIMS a huge extent reserves little
+	raw.reserve(std::min<uint64_t>(rawLen, (uint64_t)idat.size() * 1032u + 64u));
 	if (!inflateBlocks(idat.data() + 2, idat.size() - 6, raw, rawLen) || raw.size() != rawLen) return bad("corrupt deflate stream");
 	uint32_t s1 = 1, s2 = 0;
 	for (size_t i = 0; i < rawLen;)
@@ -1095,19 +1197,30 @@ extern "C" int pt_load_png(const char *path, uint8_t **outRgba, uint32_t *outW, 
 	*outH = h;
 	return PT_OK;
 }
-
-extern "C" void pt_srgb8_to_linear(const uint8_t *srgb8, uint32_t n, float *out)
+catch (const std::bad_alloc &)
 {
-	static float lut[256];
-	static bool ready = false;
-	if (!ready)
+	g_seamError = "pt_load_png: out of host memory";
+	return PT_ENOMEM;
+}
+
+namespace
+{
+struct SrgbTable
+{
+	float lut[256];
+	SrgbTable()
 	{
 		for (int i = 0; i < 256; ++i)
 		{
 			const double c = (double)i / 255.0;
 			lut[i] = (float)(c <= 0.04045 ? c / 12.92 : pow((c + 0.055) / 1.055, 2.4));
 		}
-		ready = true;
 	}
-	for (uint32_t i = 0; i < n; ++i) out[i] = lut[srgb8[i]];
+};
+}  // namespace
+
+extern "C" void pt_srgb8_to_linear(const uint8_t *srgb8, uint32_t n, float *out)
+{
+	static const SrgbTable table;  // initialised once, thread-safe (C++11 function-local static)
+	for (uint32_t i = 0; i < n; ++i) out[i] = table.lut[srgb8[i]];
 }

@@ -325,7 +325,9 @@ __device__ __forceinline__ void pt_leaf_step(const PtSceneDev &sc, const PtLaneR
 		float roy = kz == 0 ? oz : (kz == 1 ? ox : oy);
 		float roz = kz == 0 ? ox : (kz == 1 ? oy : oz);
 		uint32_t first = cur & 0x0FFFFFFFu;
-		const bool quad = kQuads && ((cur >> 28) & 7u) == PT_LEAF_QUAD;
+		// count field 7 is a quad reference only in a tree that HAS quad leaves (wave-uniform test); without them it is an
+		// ordinary leaf of eight triangles (PT_ACCEL_LEAF_SIZE(8), for which pt_build_accel builds no quads)
+		const bool quad = kQuads && sc.nQuads != 0u && ((cur >> 28) & 7u) == PT_LEAF_QUAD;
 		if (!quad)
 		{
 			uint32_t cnt = ((cur >> 28) & 7u) + 1u;

@@ -50,3 +50,23 @@ def rt(pa):
     r = pa.HipRaytracing(0)
     yield r
     r.cleanup()
+
+
+def reference_mesh_arrays(name):
+    """tinyobj::LoadObj's output for the reference's models/<name>.obj, as dumped by oracle/_ref (the reference's own vendored
+    tinyobjloader) into tests/golden/ref_seam.npz: (vertices, normals, texcoords, index_t triples, material ids, materials)."""
+    z = np.load(os.path.join(GOLDEN, "ref_seam.npz"))
+    return tuple(z[f"{name}_{k}"] for k in ("v", "vn", "vt", "idx", "mid", "mat"))
+
+
+@pytest.fixture(scope="session")
+def ref_mesh(pa):
+    """name -> Scene: the reference's mesh through the product's own loadModel half (pt_scene_from_tinyobj).  Travels to the
+    GPU box as data (the fixture), where /root/reference does not exist."""
+    cache = {}
+
+    def get(name):
+        if name not in cache:
+            cache[name] = pa.scene_from_tinyobj(*reference_mesh_arrays(name))
+        return cache[name]
+    return get

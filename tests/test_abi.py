@@ -51,6 +51,8 @@ def test_missing_library_fails_loudly(monkeypatch, pa):
 
 
 def test_product_never_imports_the_oracle():
+    """Source level: no product file imports, includes or names the oracle outside comments.  Binary level: libpt_hip.so and
+    pt_render neither export nor import an oracle symbol (pto_*) and do not depend on liboracle*.so."""
     pkg = os.path.join(ROOT, "pathtracer_amd")
     for dirpath, _, files in os.walk(pkg):
         for f in files:
@@ -60,6 +62,14 @@ def test_product_never_imports_the_oracle():
                     ("import oracle" not in line and "liboracle" not in line and "pt_oracle" not in line
                      and "obj_oracle" not in line) or line.lstrip().startswith(("//", "#", "*"))
                     for line in text.splitlines()), f"{f} references the oracle"
+    from pathtracer_amd import _lib
+    for binary in (_lib.LIB_PATH, os.path.join(pkg, "pt_render")):
+        if not os.path.exists(binary):
+            continue
+        syms = subprocess.run(["nm", "-D", binary], capture_output=True, text=True, check=True).stdout
+        assert not re.search(r"\bpto_", syms), f"{binary} links an oracle symbol"
+        needed = subprocess.run(["readelf", "-d", binary], capture_output=True, text=True, check=True).stdout
+        assert "oracle" not in needed.lower(), f"{binary} depends on an oracle library"
 
 
 def test_create_without_a_gpu_fails_cleanly(pa):

@@ -184,3 +184,121 @@ def test_camera_change_restarts_accumulation(rt, pa, cornell, ocornell):
     rt.raytrace(2)
     want2, _ = ocornell.render(view2, proj, W, H, 2, spp_per_frame=4, max_depth=6, seed=2)
     assert np.array_equal(bits(rt.readImage()), bits(want2))
+
+
+def test_tiled_checkpoint_resume_and_header_validation(pa, cornell, tmp_path):
+    """a tile-split rank that resumes must still render only its tile (the checkpoint carries the tile), and a
+    header with out-of-range fields must be refused without touching the context."""
+    import struct
+    from pathtracer_amd.api import PT_ACCUM_SUM
+    W, H = 64, 40
+    view, proj = pa.reference_camera(W, H)
+
+    def fresh():
+        r = pa.HipRaytracing(0)
+        r.buildBlas(cornell)
+        r.setCamera(view, proj)
+        return r
+
+    a = fresh()
+    a.resize(W, H)
+    a.setParams(spp_per_frame=2, max_depth=5, seed=4, max_frames=0)
+    a.setAccumMode(PT_ACCUM_SUM)
+    a.setTile(16, 0, 24, H)
+    a.raytrace(4)
+    want = a.readImage()
+    assert not want[:, :16, :3].any() and not want[:, 40:, :3].any() and want[:, 16:40, :3].any()
+    a.resetFrame()
+    a.resize(W, H)
+    a.setTile(16, 0, 24, H)
+    a.raytrace(1)
+    ck = str(tmp_path / "tile.ckpt")
+    a.saveCheckpoint(ck)
+    a.cleanup()
+    b = fresh()
+    b.loadCheckpoint(ck)
+    b.raytrace(3)
+    assert np.array_equal(bits(b.readImage()), bits(want))  # columns outside the strip are still zero
+    # corrupt headers: frame index, stride, spp, tile -- each refused, the context keeps rendering as before
+    blob = bytearray(open(ck, "rb").read())
+    assert blob[:8] == b"PTCKPT02"
+    fields = {"frame": (16, "<i", -7), "frame_big": (16, "<i", 0x7FFFFFFF), "stride": (28, "<I", 0), "spp": (36, "<i", 0),
+              "tile_w": (64, "<I", 1000)}
+    for name, (off, fmt, val) in fields.items():
+        bad = bytearray(blob)
+        struct.pack_into(fmt, bad, off, val)
+        p = tmp_path / f"bad_{name}.ckpt"
+        open(p, "wb").write(bad)
+        before = b.frame
+        with pytest.raises(pa.PathTracerError):
+            b.loadCheckpoint(str(p))
+        assert b.frame == before, name
+    open(tmp_path / "short.ckpt", "wb").write(blob[:-16])
+    with pytest.raises(pa.PathTracerError):
+        b.loadCheckpoint(str(tmp_path / "short.ckpt"))
+    # a version-1 file (no tile) still loads, as the whole image
+    v1 = b"PTCKPT01" + bytes(blob[8:56]) + bytes(blob[72:])
+    open(tmp_path / "v1.ckpt", "wb").write(v1)
+    b.loadCheckpoint(str(tmp_path / "v1.ckpt"))
+    assert b.frame == 0
+    b.cleanup()
+
+
+@pytest.mark.parametrize("n_tris", [3, 6, 40, 300])
+def test_tiny_far_geometry_matches_brute_force(rt, pa, O, n_tris):
+    """the node step of the wave kernels has no explicit empty-slot test -- an empty slot is an inverted box that
+    fails the interval test by itself, EXCEPT for a ray so far away that the node's whole extent (255 quantisation steps)
+    vanishes in the test's 1e-6 relative slack; then PT_EMPTY_CHILD is pushed and the leaf step must skip it.  Triangles of
+    size 1e-3 seen from a distance of 2e4 through a 2e-7 rad field of view make every node a stray case; 3 ... 300
+    triangles cover the three node sources of k_paths (decoded LDS records <= 8 nodes, packed LDS records <= 16, memory),
+    and the same scene is rendered instanced and on the other two pipelines.  Image and ray count == brute-force oracle."""
+    import math
+    from pathtracer_amd.api import PT_ACCEL_BVH4, PT_ACCEL_LEAF_SIZE_1, PT_PIPELINE_FUSED, PT_PIPELINE_PERSISTENT, PT_PIPELINE_SPLIT
+    rng = np.random.default_rng(n_tris)
+    ext, dist = 2e-3, 2e4
+    c = rng.uniform(-ext / 2, ext / 2, (n_tris, 1, 3))
+    size = min(8e-4, max(1.5e-4, 2.4e-3 / math.sqrt(n_tris)))
+    tri = (c + rng.uniform(-size, size, (n_tris, 3, 3))).astype(np.float32)
+    verts = np.zeros((n_tris * 3, 11), dtype=np.float32)
+    verts[:, 0:3] = tri.reshape(-1, 3)
+    verts[:, 3:6] = [0, 0, 1]
+    verts[:, 6:9] = 1.0
+    mats = np.array([[0.8, 0.8, 0.8, 0, 0, 0], [0, 0, 0, 15, 15, 15]], dtype=np.float32)
+    sc = pa.Scene(verts, np.arange(n_tris * 3, dtype=np.uint32), mats, (np.arange(n_tris) % 2).astype(np.uint32))
+    W, H = 64, 48
+    view = pa.look_at((0.0, 0.0, dist), (0.0, 0.0, 0.0), (0, 1, 0))
+    proj = pa.perspective(2.0 * math.atan(0.6 * ext / dist), W / H, 1.0, 4.0 * dist)
+    proj[5] *= -1
+    args = dict(spp_per_frame=2, max_depth=3, tmax=1e5, seed=3)
+    osc = O.OracleScene(sc.vertices, sc.indices, sc.materials, sc.mat_indices, use_bvh=False)
+    want, rays = osc.render(view, proj, W, H, frames=2, **args)
+    assert want[..., :3].max() == 15.0 and 0.01 < (want[..., :3].sum(-1) > 0).mean() < 0.98
+    for flags in (PT_ACCEL_BVH4 | PT_ACCEL_LEAF_SIZE_1, 2):  # LBVH with one triangle per leaf (3-child nodes), PLOC default
+        rt.buildBlas(sc, flags)
+        rt.resize(W, H)
+        rt.setCamera(view, proj)
+        rt.setParams(max_frames=0, **args)
+        for pipe in (PT_PIPELINE_PERSISTENT, PT_PIPELINE_FUSED, PT_PIPELINE_SPLIT):
+            rt.setPipeline(pipe)
+            rt.resetFrame()
+            rt.resetStats()
+            rt.raytrace(2)
+            assert np.array_equal(bits(rt.readImage()), bits(want)), (flags, pipe)
+            assert rt.stats().rays_total == rays, (flags, pipe)
+    # instanced: two copies side by side, far away as well
+    xf = np.array([[1, 0, 0, -ext, 0, 1, 0, 0, 0, 0, 1, 0], [1, 0, 0, ext, 0, 1, 0, 0, 0, 0, 1, 0]], dtype=np.float32)
+    proj2 = pa.perspective(2.0 * math.atan(1.8 * ext / dist), W / H, 1.0, 4.0 * dist)
+    proj2[5] *= -1
+    osc2 = O.OracleScene(sc.vertices, sc.indices, sc.materials, sc.mat_indices, use_bvh=False, instances=xf)
+    want2, rays2 = osc2.render(view, proj2, W, H, frames=2, **args)
+    assert want2[..., :3].max() == 15.0
+    rt.setPipeline(PT_PIPELINE_PERSISTENT)
+    rt.uploadScene(sc)
+    rt.setInstances(xf)
+    rt.buildBlas(None, PT_ACCEL_BVH4 | PT_ACCEL_LEAF_SIZE_1)
+    rt.resize(W, H)
+    rt.setCamera(view, proj2)
+    rt.setParams(max_frames=0, **args)
+    rt.raytrace(2)
+    assert np.array_equal(bits(rt.readImage()), bits(want2))
+    assert rt.stats().rays_total == rays2

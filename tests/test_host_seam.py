@@ -77,6 +77,41 @@ def test_product_loader_matches_oracle_on_reference_models(model, pa):
         assert np.array_equal(getattr(got, k).view(np.uint32), want[k].view(np.uint32)), (model, k)
 
 
+@pytest.mark.parametrize("model", ["cornell", "plane", "teapot", "viking_room"])
+def test_scene_from_tinyobj_fixture_product_equals_oracle(model, pa):
+    """loadModel's de-duplication loop alone, over the arrays the reference's own tinyobjloader produced (fixture): product
+    (pt_scene_from_tinyobj) == oracle, bit for bit; where the reference's files exist also == pt_load_obj on the file.
+    This is how the GPU box gets viking_room / teapot (BASELINE configs[2], [3]): as data, not as files."""
+    import obj_oracle as oo
+    from conftest import reference_mesh_arrays
+    arrays = reference_mesh_arrays(model)
+    got = pa.scene_from_tinyobj(*arrays)
+    want = oo.model_from_tinyobj(oo.tinyobj_from_arrays(*arrays))
+    for k in ("vertices", "indices", "materials", "mat_indices"):
+        assert np.array_equal(getattr(got, k).view(np.uint32), want[k].view(np.uint32)), (model, k)
+    if HAVE_MODELS:
+        ref = pa.load_obj(os.path.join(REFERENCE_MODELS, model + ".obj"))
+        for k in ("vertices", "indices", "materials", "mat_indices"):
+            assert np.array_equal(getattr(got, k).view(np.uint32), getattr(ref, k).view(np.uint32)), (model, k)
+    # SURVEY.md section 8(c) facts
+    facts = {"cornell": (32, 64, 5), "plane": (2, None, 1), "teapot": (6320, None, 1), "viking_room": (3828, 4725, 1)}[model]
+    assert got.n_tris == facts[0] and got.materials.shape[0] == facts[2]
+    if facts[1] is not None:
+        assert got.vertices.shape[0] == facts[1]
+
+
+def test_scene_from_tinyobj_rejects_bad_arrays(pa):
+    v = np.zeros(9, dtype=np.float32)
+    idx = np.array([[0, -1, -1], [1, -1, -1], [7, -1, -1]], dtype=np.int32)
+    with pytest.raises(pa.PathTracerError):
+        pa.scene_from_tinyobj(v, [], [], idx, [-1], np.zeros((0, 6), np.float32))  # vertex 7 does not exist
+    idx[2, 0] = 2
+    with pytest.raises(pa.PathTracerError):
+        pa.scene_from_tinyobj(v, [], [], idx, [3], np.zeros((0, 6), np.float32))  # material 3 does not exist
+    sc = pa.scene_from_tinyobj(v, [], [], idx, [-1], np.zeros((0, 6), np.float32))
+    assert sc.n_tris == 1 and list(sc.mat_indices) == [0] and list(sc.vertices[0, 3:6]) == [0.0, 0.0, 1.0]  # degenerate -> (0,0,1)
+
+
 def test_generated_cornell_equals_reference_tinyobj_output(pa, tmp_path):
     """The Cornell box emitted by pathtracer_amd.scenes parses to exactly what the reference's
     tinyobjloader makes of the reference's models/cornell.obj (fixture), signs of zero included."""
