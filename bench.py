@@ -1,43 +1,54 @@
 #!/usr/bin/env python3
-"""Headline benchmark: Mrays/s (+ samples/px/s) of the wavefront path tracer on the Cornell box,
-1920x1080, max depth 8 (BASELINE.json metric; workload = configs[1], 16 spp per frame so that the
-default 64 steps are the 1024 spp of that config).
+"""Headline benchmark: Mrays/s (+ samples/px/s) of the path tracer on the Cornell box, 1920x1080, max depth 8
+(BASELINE.json metric; workload = configs[1], 16 spp per frame so that the default 64 steps are the 1024 spp of
+that config).
 
-  python bench.py --gpus N --steps K --warmup W
+  python bench.py --gpus N --steps K --warmup W [--split streams|tiles] [--scene cornell|soup]
 
-One "step" = one pass of the hot path over one batch = one frame (W*H*spp_per_frame paths pushed
-through generate -> (extend -> shade) x depth -> accumulate).  A "ray" is one closest-hit query
-(one traceRayEXT of the reference).  With N > 1 (launched by torch.distributed.run, one rank per
-GPU) every rank renders K disjoint global frames (rank r renders frames r, r+N, ...: weak
-scaling) against a replicated scene/BVH into raw sums, and the images are combined by one RCCL
-reduce(sum) over xGMI inside the timed region.
+One "step" = one pass of the hot path over one batch = one frame: W*H*spp_per_frame paths traced from the camera
+ray to termination by the persistent path kernel k_paths (generate -> traverse -> shade -> ... inside one launch,
+several frames per launch), then folded into the accumulation image.  A "ray" is one closest-hit query (one
+traceRayEXT of the reference).
 
-Rank 0 prints ONE JSON line.  `roofline` prices the dominant kernel (k_extend) against HBM:
-achieved = algorithmic bytes per launch / mean launch duration, both measured in this run (HIP
-events on the library's stream, averaged over the timed steps).  `cpu_baseline` is the CPU oracle
-(oracle/pt_oracle.c, "port") timed on a bounded sample of the same workload on rank 0 at N=1.
+N > 1: one process per GPU over RCCL.  When the process was NOT started by torch.distributed.run (no WORLD_SIZE in
+the environment) it starts `python -m torch.distributed.run --nproc-per-node N ... bench.py <same arguments>` as a
+child process BEFORE anything touches the GPU, relays rank 0's JSON line and exits with the child's code.
+  --split streams (default; configs 2-4): rank r renders the global frames r, r+N, ... against a replicated
+      scene/BVH into raw sums; one RCCL reduce(sum) of the image inside the timed region.  Weak scaling.
+  --split tiles (config 5): every rank renders the SAME frames on its own column strip; same reduce.  Strong scaling.
+
+Rank 0 prints ONE JSON line.  `roofline` prices the dominant kernel (k_paths) against the bound that binds it --
+VALU issue on the cache-resident Cornell box -- and `roofline_hbm` keeps the HBM figure: achieved = algorithmic
+units per launch / mean launch duration, both measured in this run (HIP events on the library's stream around
+every launch of the timed region).  The per-ray constants that only hardware counters can give (VALU wave
+instructions per ray, HBM bytes per ray) come from the committed rocprofv3 --pmc summaries under profiles/.
+`cpu_baseline` is the CPU oracle (oracle/pt_oracle.c, "port") timed on a bounded sample of the same workload on
+rank 0 at N=1; `reference_lavapipe` says why the reference-on-lavapipe leg cannot run on this box.
 """
 from __future__ import annotations
 
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
-
-import numpy as np
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
+HBM_PEAK_GBS = 8000.0   # MI355X HBM3E spec peak (MI355X_MICROARCH.md, chip-level parameters)
+CUS, SIMDS_PER_CU, MAX_CLOCK_GHZ = 256, 4, 2.4
+# a wave64 VALU instruction issues over 2 cycles on a SIMD-32 (MI355X_MICROARCH.md, wave scheduling)
+VALU_PEAK_GINST = CUS * SIMDS_PER_CU * MAX_CLOCK_GHZ / 2.0  # 1228.8 G wave-instructions/s
 
 
-def parse():
+def parse(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=64)
-    ap.add_argument("--warmup", type=int, default=4)
+    ap.add_argument("--warmup", type=int, default=8)
     ap.add_argument("--width", type=int, default=1920)
     ap.add_argument("--height", type=int, default=1080)
     ap.add_argument("--spp-per-frame", type=int, default=16)
@@ -47,10 +58,54 @@ def parse():
     ap.add_argument("--out-image", default="")
     ap.add_argument("--pipeline", choices=["persistent", "fused", "split"], default="persistent")
     ap.add_argument("--builder", choices=["ploc", "lbvh"], default="ploc", help="BVH2 construction before the BVH4 collapse")
-    ap.add_argument("--force-dist", action="store_true", help="initialise torch.distributed/RCCL even for one rank (rehearses the N>1 path on one GPU)")
-    return ap.parse_args()
+    ap.add_argument("--split", choices=["streams", "tiles"], default="streams",
+                    help="multi-GPU partitioning: disjoint sample streams (frames) or image tiles (column strips)")
+    ap.add_argument("--scene", choices=["cornell", "soup"], default="cornell",
+                    help="cornell = BASELINE configs[1] (the metric); soup = the procedural triangles of configs[4]")
+    ap.add_argument("--tris", type=float, default=1e6, help="--scene soup: number of triangles")
+    ap.add_argument("--force-dist", action="store_true",
+                    help="go through torch.distributed/RCCL even for one rank (rehearses the N>1 path on one GPU)")
+    return ap.parse_args(argv)
 
 
+# ------------------------------------------------------------------------------------------ self-launch ----
+def free_port():
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def launch_command(n_ranks, argv, port):
+    """The torch.distributed.run command line that starts `n_ranks` copies of this script (one per GPU)."""
+    return [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n_ranks}",
+            "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__), *argv]
+
+
+def self_launch(n_ranks, argv):
+    """Runs the ranks as CHILD processes (this process has not touched the GPU and never will), relays the one JSON
+    line rank 0 prints to stdout and everything else to stderr, returns the children's exit code."""
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # dmabuf IPC: RCCL needs it on this driver
+    env.setdefault("OMP_NUM_THREADS", "4")
+    cmd = launch_command(n_ranks, argv, free_port())
+    print("[bench] starting: " + " ".join(cmd), file=sys.stderr, flush=True)
+    proc = subprocess.Popen(cmd, stdout=subprocess.PIPE, env=env, text=True)
+    lines = 0
+    for line in proc.stdout:
+        if line.startswith('{"metric"'):
+            lines += 1
+            sys.stdout.write(line)
+            sys.stdout.flush()
+        else:
+            sys.stderr.write(line)
+    rc = proc.wait()
+    if rc == 0 and lines != 1:
+        print(f"[bench] expected one JSON line from rank 0, saw {lines}", file=sys.stderr)
+        return 1
+    return rc
+
+
+# ------------------------------------------------------------------------------------------------ helpers ----
 class _DevArray:
     """Exposes a raw device pointer to torch through __cuda_array_interface__ (zero copy)."""
 
@@ -59,21 +114,79 @@ class _DevArray:
                                          "version": 2, "strides": None}
 
 
+def probe_lavapipe():
+    """north_star asks for the reference pipeline headless on Mesa lavapipe beside the GPU number.  That needs a Vulkan
+    loader, a lavapipe ICD with VK_KHR_ray_tracing_pipeline + VK_KHR_shader_clock, and a headless harness for a program
+    that requires a GLFW window surface (main.cpp:239-279).  Reports what is there."""
+    import ctypes.util
+    import glob
+    import shutil
+    loader = ctypes.util.find_library("vulkan")
+    icds = [p for d in ("/usr/share/vulkan/icd.d", "/etc/vulkan/icd.d", "/usr/local/share/vulkan/icd.d")
+            for p in glob.glob(os.path.join(d, "*.json"))]
+    lvp = [p for p in icds if "lvp" in os.path.basename(p)]
+    tools = [t for t in ("glslangValidator", "glslc", "vulkaninfo") if shutil.which(t)]
+    if loader and lvp:
+        return f"present but not driven: loader {loader}, ICD {lvp[0]} (the reference needs a window surface and a swapchain)"
+    return ("unavailable: Vulkan loader " + (loader or "not found (ctypes.util.find_library('vulkan') is None)") +
+            "; lavapipe ICD " + (lvp[0] if lvp else f"not found ({len(icds)} ICD manifests under */vulkan/icd.d)") +
+            "; GLSL/Vulkan tools on PATH: " + (", ".join(tools) if tools else "none") +
+            "; no package index to install them; the reference additionally needs a GLFW window surface (main.cpp:239-279)")
+
+
+def load_profile_json(name):
+    try:
+        with open(os.path.join(ROOT, "profiles", name)) as f:
+            return json.load(f)
+    except Exception:
+        return None
+
+
+def build_scene(a, pa):
+    """(scene, view, proj, tmax, description)"""
+    import math
+    W, H = a.width, a.height
+    if a.scene == "cornell":
+        view, proj = pa.reference_camera(W, H)
+        return pa.scenes.cornell_box(), view, proj, 1e4, "Cornell box"
+    n = int(a.tris)
+    extent = 1000.0 * (n / 1e8) ** (1.0 / 3.0)  # the density of configs[4]: 1e8 triangles in a 1000^3 cube
+    sc = pa.scenes.random_triangles(n, extent=extent, edge=1.0)
+    c = extent * 0.5
+    view = pa.look_at((c, c * 1.2, c + extent * 1.6), (c, c * 0.9, c), (0, 1, 0))
+    proj = pa.perspective(math.radians(45.0), W / H, 0.1, extent * 10)
+    proj[5] *= -1  # main.cpp:1475
+    return sc, view, proj, 1e6, f"procedural soup of {n} triangles"
+
+
+# --------------------------------------------------------------------------------------------------- main ----
 def main():
     a = parse()
     n_gpus = a.gpus
+    launched = "WORLD_SIZE" in os.environ
+    if (n_gpus > 1 or a.force_dist) and not launched:
+        # plain `python bench.py --gpus N`: become the launcher.  Nothing above has imported torch or the library.
+        sys.exit(self_launch(max(1, n_gpus), sys.argv[1:]))
+
+    import numpy as np
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     dist = None
     torch = None
+    rccl = None
     if n_gpus > 1 or a.force_dist:
         import torch
         import torch.distributed as dist
         if world != n_gpus and not a.force_dist:
-            raise SystemExit(f"--gpus {n_gpus} needs WORLD_SIZE={n_gpus} (launch with torch.distributed.run); got {world}")
+            raise SystemExit(f"--gpus {n_gpus} but WORLD_SIZE={world}")
         torch.cuda.set_device(local_rank)
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        world = dist.get_world_size()  # as RCCL sees it
+        try:
+            rccl = ".".join(str(x) for x in torch.cuda.nccl.version())
+        except Exception:
+            rccl = "unknown"
 
     import pathtracer_amd as pa
     from pathtracer_amd.api import (PT_ACCUM_MEAN, PT_ACCUM_SUM, PT_PIPELINE_FUSED, PT_PIPELINE_SPLIT, PT_PROFILE_KERNELS,
@@ -81,16 +194,20 @@ def main():
     from pathtracer_amd import multigpu
 
     W, H, S, D = a.width, a.height, a.spp_per_frame, a.depth
-    scene = pa.scenes.cornell_box()
-    view, proj = pa.reference_camera(W, H)
+    scene, view, proj, tmax, scene_name = build_scene(a, pa)
     rt = pa.HipRaytracing(local_rank)
     rt.buildBlas(scene, pa.api.PT_ACCEL_BVH4_PLOC if a.builder == "ploc" else pa.api.PT_ACCEL_BVH4)
     rt.buildTlas()
     rt.resize(W, H)
     rt.setCamera(view, proj)
-    rt.setParams(spp_per_frame=S, max_depth=D, tmin=1e-3, tmax=1e4, seed=0, max_frames=0)
-    first, stride = multigpu.frame_schedule(rank, world)
-    rt.setFrameSchedule(first=first, stride=stride)
+    rt.setParams(spp_per_frame=S, max_depth=D, tmin=1e-3, tmax=tmax, seed=0, max_frames=0)
+    tiles = a.split == "tiles"
+    if tiles:
+        rt.setFrameSchedule(first=0, stride=1)  # every rank renders the same frames ...
+        rt.setTile(*multigpu.tile_schedule(rank, world, W, H))  # ... on its own column strip
+    else:
+        first, stride = multigpu.frame_schedule(rank, world)
+        rt.setFrameSchedule(first=first, stride=stride)
     rt.setAccumMode(PT_ACCUM_SUM if dist is not None else PT_ACCUM_MEAN)
     rt.setPipeline({"fused": PT_PIPELINE_FUSED, "split": PT_PIPELINE_SPLIT, "persistent": pa.api.PT_PIPELINE_PERSISTENT}[a.pipeline])
 
@@ -111,7 +228,7 @@ def main():
             multigpu.reduce_sum_image(img_t, dist, dst=0)
             torch.cuda.synchronize()
 
-    # ---- untimed: traversal statistics for the roofline (node visits / triangle tests per ray) ----
+    # ---- untimed: traversal statistics (node visits / triangle tests per ray, lane utilisation of the steps) ----
     rt.setProfiling(PT_PROFILE_TRAVERSAL)
     rt.raytrace(2)  # frame 0 has centred jitter; include a jittered one
     rt.synchronize()
@@ -160,79 +277,105 @@ def main():
     if a.out_image and rank == 0:
         img = rt.readImage()
         if dist is not None:
-            multigpu.finalize_mean(img, world * a.steps)
+            multigpu.finalize_mean(img, a.steps if tiles else world * a.steps)
         np.save(a.out_image, img)
 
     if rank == 0:
         mrays = rays_all / dt_max / 1e6
-        total_spp = a.steps * S * world
-        # dominant kernel: k_extend.  Algorithmic HBM bytes per ray: 32 B ray record read
-        # + 16 B hit record written; the scene (2 KB for Cornell) is read once per launch.  Node/triangle
-        # fetches (nodes*64 + tris*48 B/ray) are cache traffic on this scene and reported separately.
-        # Fused pipeline (default): the dominant kernel is k_bounce = traverse + shade + compact; per ray it
-        # must read the 32 B ray record, the 16 B throughput record of every ray that hits (p_hit) and write
-        # a 48 B record for every survivor (p_alive); the hit record never leaves the chip.
+        total_spp = a.steps * S * (1 if tiles else world)
         scene_bytes = st.bvh_nodes * 64.0 + 3 * st.bvh_tris * 48.0
-        paths_total = float(W) * H * S * a.steps
-        p_alive = max(0.0, (rays_local - paths_total) / max(1.0, rays_local))  # rays of bounce >= 1 = survivors
-        p_prim = paths_total / max(1.0, rays_local)
+        paths_local = float(st.paths_last_frame) * a.steps
+        p_alive = max(0.0, (rays_local - paths_local) / max(1.0, rays_local))  # rays of bounce >= 1 = survivors
+        p_prim = paths_local / max(1.0, rays_local)
+        kernel = {"persistent": "k_paths", "fused": "k_bounce"}.get(a.pipeline, "k_extend")
         if a.pipeline == "persistent":
-            # k_paths: a new path writes its 16 B state record and zeroes its 16 B radiance record; a hit reads
-            # the state record; a survivor writes it back and makes one round trip (32 B out, 32 B in) through
-            # the wave's ring.  Camera rays never exist in memory.
-            bytes_per_ray_extend = 32.0 * p_prim + 16.0 * p_hit + 80.0 * p_alive
+            # k_paths: a new path writes its 16 B state record and zeroes its 16 B radiance record; a hit reads the state
+            # record; a survivor writes it back and makes one round trip (32 B out, 32 B in) through the wave's ring.
+            # Camera rays and hit records never exist in memory.
+            bytes_per_ray = 32.0 * p_prim + 16.0 * p_hit + 80.0 * p_alive
         elif a.pipeline == "fused":
-            bytes_per_ray_extend = 32.0 + 16.0 * p_hit + 48.0 * p_alive
+            # k_bounce (one launch per bounce): 32 B ray record read, 16 B throughput record per hit, 48 B per survivor
+            bytes_per_ray = 32.0 + 16.0 * p_hit + 48.0 * p_alive
         else:
-            bytes_per_ray_extend = 48.0
+            # k_extend: 32 B ray record read + 16 B hit record written
+            bytes_per_ray = 48.0
         cache_bytes_per_ray = nodes_per_ray * 64.0 + tris_per_ray * 48.0
         # whole-step figure of SURVEY.md 8(d): 160 B queue traffic + traversal + 172 B closest-hit gather
         bytes_per_ray_step = 160.0 + nodes_per_ray * 64.0 + tris_per_ray * 48.0 + 172.0 * p_hit
-        ext_ms = st.extend_ms_total / max(1, st.extend_launches)
-        rays_per_launch = rays_local / max(1, st.extend_launches)
-        achieved = (rays_per_launch * bytes_per_ray_extend + scene_bytes) / (ext_ms * 1e-3) / 1e9 if ext_ms > 0 else 0.0
-        traffic = None
-        tpath = os.path.join(ROOT, "profiles", {"persistent": "traffic_paths.json", "fused": "traffic_bounce.json"}.get(a.pipeline, "traffic_extend.json"))
-        if os.path.exists(tpath):
-            try:
-                with open(tpath) as f:
-                    traffic = json.load(f).get("hbm_bytes_per_launch")
-            except Exception:
-                traffic = None
+        launches = max(1, st.extend_launches)
+        ext_ms = st.extend_ms_total / launches
+        rays_per_launch = rays_local / launches
+        sec = ext_ms * 1e-3
+        hbm_achieved = (rays_per_launch * bytes_per_ray + scene_bytes) / sec / 1e9 if sec > 0 else 0.0
+        # hardware-counter constants of this kernel on this workload, from the committed --pmc summaries (per RAY, so that
+        # they compare with bytes_per_ray whatever the launch length)
+        tj = load_profile_json({"persistent": "traffic_paths.json", "fused": "traffic_bounce.json"}.get(a.pipeline, "none")) \
+            if a.scene == "cornell" else None
+        traffic_per_ray = tj.get("hbm_bytes_per_ray") if tj else None
+        traffic = round(traffic_per_ray * rays_per_launch) if traffic_per_ray else None
+        hbm = {"bound": "hbm", "achieved": round(hbm_achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+               "frac": round(hbm_achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
+               "traffic_bytes_per_ray": round(traffic_per_ray, 2) if traffic_per_ray else None,
+               "bytes_per_ray": round(bytes_per_ray, 2),
+               "traffic_over_algorithmic": round(traffic_per_ray / bytes_per_ray, 3) if traffic_per_ray else None,
+               "kernel": kernel, "launch_ms": round(ext_ms, 4), "rays_per_launch": rays_per_launch,
+               "p_alive": round(p_alive, 4), "p_hit": round(p_hit, 4),
+               "cache_served_bytes_per_ray": round(cache_bytes_per_ray, 2),
+               "cache_served_gbs": round(rays_per_launch * cache_bytes_per_ray / sec / 1e9, 1) if sec > 0 else 0.0,
+               "nodes_per_ray": round(nodes_per_ray, 3), "tris_per_ray": round(tris_per_ray, 3)}
+        vj = load_profile_json("valu_paths.json") if (a.pipeline == "persistent" and a.scene == "cornell") else None
+        valu = None
+        if vj and vj.get("valu_wave_insts_per_ray"):
+            ipr = float(vj["valu_wave_insts_per_ray"])
+            ginst = rays_per_launch * ipr / sec / 1e9 if sec > 0 else 0.0
+            held = float(vj.get("clock_ghz") or MAX_CLOCK_GHZ)
+            valu = {"bound": "valu", "achieved": round(ginst, 2), "peak": VALU_PEAK_GINST, "unit": "Ginst/s",
+                    "frac": round(ginst / VALU_PEAK_GINST, 5), "traffic": traffic,
+                    "note": "VALU wave-instruction issue: achieved = SQ_INSTS_VALU per ray (committed rocprofv3 --pmc pass, "
+                            "profiles/valu_paths.json) x rays per launch / launch duration (live); peak = 256 CUs x 4 SIMDs x "
+                            "2.4 GHz / 2 cycles per wave64 instruction.  Cheapest-instruction peak: cmp/cndmask/cvt/min/max "
+                            "issue at ~1.5x and rcp/sqrt at ~3x that cost, so 1.0 is not reachable by this mix",
+                    "kernel": kernel, "launch_ms": round(ext_ms, 4), "rays_per_launch": rays_per_launch,
+                    "valu_wave_insts_per_ray": round(ipr, 3), "valu_lane_util": vj.get("valu_lane_util"),
+                    "clock_ghz_held_in_profile": held,
+                    "frac_at_held_clock": round(ginst / (CUS * SIMDS_PER_CU * held / 2.0), 5),
+                    "extend_mrays_per_s": round(rays_per_launch / sec / 1e6, 1) if sec > 0 else 0.0,
+                    "profile": vj.get("source")}
+        # the bound that binds = the larger fraction of its peak
+        if valu and valu["frac"] >= hbm["frac"]:
+            roofline, other_key, other = valu, "roofline_hbm", hbm
+        else:
+            roofline, other_key, other = hbm, "roofline_valu", valu
         out = {
             "metric": "Mrays/s", "value": round(mrays, 2), "unit": "Mrays/s", "n_gpus": world, "steps": a.steps,
             "warmup": a.warmup, "ms_per_step": round(dt_max / a.steps * 1e3, 4), "higher_is_better": True,
-            "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": f"Cornell box {W}x{H}, {S} spp/frame x {a.steps} frames/GPU, max depth {D}, "
-                                   f"wavefront path tracer, quantised BVH4 ({a.builder.upper()}) (BASELINE.json configs[1])",
-                       "width": W, "height": H, "spp_per_frame": S, "max_depth": D,
-                       "total_spp": total_spp, "parallelism": f"sample-stream x{world}"},
+            "scaling": "strong" if tiles else "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"{scene_name} {W}x{H}, {S} spp/frame x {a.steps} frames"
+                                   f"{'' if tiles else '/GPU'}, max depth {D}, persistent wavefront path tracer, quantised BVH4 "
+                                   f"({a.builder.upper()})" + (" (BASELINE.json configs[1])" if a.scene == "cornell" else
+                                                               " (BASELINE.json configs[4] generator)"),
+                       "width": W, "height": H, "spp_per_frame": S, "max_depth": D, "total_spp": total_spp,
+                       "parallelism": (f"image tiles (column strips) x{world}" if tiles else f"sample-stream x{world}")},
             "samples_per_px_per_s": round(total_spp / dt_max, 3),
             "rays_per_step_per_gpu": rays_local / a.steps,
-            "roofline": {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
-                         "kernel": {"persistent": "k_paths", "fused": "k_bounce"}.get(a.pipeline, "k_extend"), "p_alive": round(p_alive, 4),
-                         "launch_ms": round(ext_ms, 4), "rays_per_launch": rays_per_launch,
-                         "bytes_per_ray": round(bytes_per_ray_extend, 2),
-                         "cache_served_bytes_per_ray": round(cache_bytes_per_ray, 2),
-                         "cache_served_gbs": round(rays_per_launch * cache_bytes_per_ray / (ext_ms * 1e-3) / 1e9, 1)
-                         if ext_ms > 0 else 0.0,
-                         "extend_mrays_per_s": round(rays_per_launch / (ext_ms * 1e-3) / 1e6, 1) if ext_ms > 0 else 0.0,
-                         "nodes_per_ray": round(nodes_per_ray, 3),
-                         "tris_per_ray": round(tris_per_ray, 3), "p_hit": round(p_hit, 4)},
-            "roofline_step": {"note": "SURVEY.md 8(d) whole-step formula; its traversal/gather terms are L1/L2 traffic on this "
-                                      "2.5 KB scene, so frac may exceed 1 -- HBM-only accounting is `roofline`",
+            "roofline": roofline, other_key: other,
+            "roofline_step": {"note": "SURVEY.md 8(d) whole-step formula; its traversal/gather terms are L1/L2 traffic on a "
+                                      "cache-resident scene, so frac may exceed 1 -- HBM-only accounting is roofline_hbm",
                               "bytes_per_ray": round(bytes_per_ray_step, 2),
                               "achieved": round(mrays / world * 1e6 * bytes_per_ray_step / 1e9, 2), "unit": "GB/s",
                               "frac": round(mrays / world * 1e6 * bytes_per_ray_step / 1e9 / HBM_PEAK_GBS, 5),
                               "queue_only_frac": round(mrays / world * 1e6 * 160.0 / 1e9 / HBM_PEAK_GBS, 5)},
             "kernel_ms": {{"persistent": "paths_mean", "fused": "bounce_mean"}.get(a.pipeline, "extend_mean"): round(ext_ms, 4),
                           ("accumulate_mean" if a.pipeline == "persistent" else "shade_mean"):
-                          round(st.shade_ms_total / max(1, st.shade_launches), 4)},
-            "pipeline": a.pipeline, "builder": a.builder, "divergence": divergence,
+                          round(st.shade_ms_total / max(1, st.shade_launches), 4),
+                          "launches": int(st.extend_launches)},
+            "pipeline": a.pipeline, "builder": a.builder, "split": a.split, "divergence": divergence,
             "bvh": {"nodes": st.bvh_nodes, "depth": st.bvh_depth, "tris": st.bvh_tris, "build_ms": round(st.build_ms, 3)},
+            "distributed": ({"backend": "nccl (RCCL)", "rccl_version": rccl, "world_size": world,
+                             "launcher": "torch.distributed.run"} if dist is not None else None),
+            "reference_lavapipe": probe_lavapipe(),
         }
-        if world == 1 and not a.no_cpu_baseline:
+        if world == 1 and not a.no_cpu_baseline and a.scene == "cornell":
             out["cpu_baseline"] = cpu_baseline(scene, view, proj, W, H, S, D, a.cpu_sample_frames)
         print(json.dumps(out), flush=True)
 

@@ -1,0 +1,82 @@
+"""CPU: bench.py's self-launch for N > 1 (`python bench.py --gpus N` from a plain shell must start its own
+ranks).  No GPU here: the launcher is exercised with torch.distributed.run over a stand-in rank script (gloo-free: the
+stand-in only prints), and the real command line is checked textually."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+from conftest import ROOT
+
+sys.path.insert(0, ROOT)
+import bench  # noqa: E402  (importing bench touches neither torch nor the GPU)
+
+
+def test_importing_bench_loads_neither_torch_nor_the_library():
+    code = ("import sys; sys.path.insert(0, %r); import bench; "
+            "assert 'torch' not in sys.modules and 'pathtracer_amd' not in sys.modules; print('clean')" % ROOT)
+    out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, check=True).stdout
+    assert out.strip() == "clean"
+
+
+def test_launch_command_is_the_drivers_form():
+    cmd = bench.launch_command(4, ["--gpus", "4", "--steps", "20", "--warmup", "5"], 29511)
+    assert cmd[:3] == [sys.executable, "-m", "torch.distributed.run"]
+    assert "--nnodes=1" in cmd and "--nproc-per-node=4" in cmd
+    assert cmd[cmd.index("--master-addr") + 1] == "127.0.0.1" and cmd[cmd.index("--master-port") + 1] == "29511"
+    assert cmd[-7] == os.path.join(ROOT, "bench.py") and cmd[-6:] == ["--gpus", "4", "--steps", "20", "--warmup", "5"]
+
+
+def test_main_becomes_the_launcher_before_touching_the_gpu(monkeypatch):
+    seen = {}
+
+    def fake(n, argv):
+        seen["n"], seen["argv"] = n, list(argv)
+        seen["torch_loaded"] = "torch" in sys.modules and hasattr(sys.modules["torch"], "cuda") and \
+            sys.modules["torch"].cuda.is_initialized()
+        return 7
+
+    monkeypatch.setattr(bench, "self_launch", fake)
+    monkeypatch.delenv("WORLD_SIZE", raising=False)
+    monkeypatch.setattr(sys, "argv", ["bench.py", "--gpus", "2", "--steps", "3"])
+    with pytest.raises(SystemExit) as e:
+        bench.main()
+    assert e.value.code == 7 and seen["n"] == 2 and seen["argv"] == ["--gpus", "2", "--steps", "3"] and not seen["torch_loaded"]
+    # --force-dist on one GPU goes through the same launcher
+    monkeypatch.setattr(sys, "argv", ["bench.py", "--force-dist"])
+    with pytest.raises(SystemExit):
+        bench.main()
+    assert seen["n"] == 1
+
+
+def test_self_launch_runs_ranks_and_relays_one_line(monkeypatch, tmp_path, capfd):
+    """Two real ranks under torch.distributed.run (a stand-in script: rank 0 prints the JSON line, both print noise)."""
+    script = tmp_path / "rank.py"
+    script.write_text("import os, json\n"
+                      "r, w = int(os.environ['RANK']), int(os.environ['WORLD_SIZE'])\n"
+                      "print('noise from rank', r, flush=True)\n"
+                      "if r == 0: print(json.dumps({'metric': 'Mrays/s', 'n_gpus': w}), flush=True)\n")
+    real = bench.launch_command
+
+    def cmd(n, argv, port):
+        c = real(n, argv, port)
+        c[c.index(os.path.join(ROOT, "bench.py"))] = str(script)
+        return c
+
+    monkeypatch.setattr(bench, "launch_command", cmd)
+    rc = bench.self_launch(2, [])
+    out, err = capfd.readouterr()
+    assert rc == 0
+    lines = [ln for ln in out.splitlines() if ln.strip()]
+    assert len(lines) == 1 and json.loads(lines[0]) == {"metric": "Mrays/s", "n_gpus": 2}
+    assert "noise from rank 1" in err
+    # a failing rank's exit code comes back
+    script.write_text("import sys; sys.exit(3)\n")
+    assert bench.self_launch(2, []) != 0
+
+
+def test_lavapipe_probe_reports_what_it_looked_for():
+    msg = bench.probe_lavapipe()
+    assert msg.startswith(("unavailable:", "present")) and "ICD" in msg

@@ -299,6 +299,7 @@ def test_tiny_far_geometry_matches_brute_force(rt, pa, O, n_tris):
     rt.resize(W, H)
     rt.setCamera(view, proj2)
     rt.setParams(max_frames=0, **args)
+    rt.resetStats()
     rt.raytrace(2)
     assert np.array_equal(bits(rt.readImage()), bits(want2))
     assert rt.stats().rays_total == rays2
