@@ -8,6 +8,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <mutex>
 #include <new>
 #include <string>
 #include <vector>
@@ -26,6 +27,30 @@ struct EventPair
 {
 	hipEvent_t begin, mid, end;
 };
+}  // namespace
+
+// ---- scratch of the allocation-free entry point pt_render_frames_noalloc (include/pt_hip.h) ----
+// What pt_render_frames allocates on demand (the LCG skip-ahead table, the per-path state and radiance records, the
+// wave-private survivor rings), at a fixed maximum size, in a file-scope device array: every GPU the library runs on holds
+// its own copy at its own address until the process ends.  Host code never uses the array's name as an address: pt_create
+// asks hipGetSymbolAddress once per device (g_scratchPtr) and everything below works with that pointer.
+#define PT_NOALLOC_WAVES 1024u                 // single-wave workgroups of the launch (4 per CU)
+#define PT_NOALLOC_MAX_RECORDS (1u << 18)      // paths per launch: ceil(tile pixels / 64) * 64 * spp_per_frame
+#define PT_NOALLOC_MAX_SPP 256u
+namespace
+{
+constexpr size_t kNaRingBytes = (size_t)PT_NOALLOC_WAVES * PT_PATHS_RING * sizeof(float4);  // 4 MiB
+constexpr size_t kNaRecBytes = (size_t)PT_NOALLOC_MAX_RECORDS * sizeof(float4);             // 4 MiB
+constexpr size_t kNaOffRingO = 0, kNaOffRingD = kNaRingBytes, kNaOffState = 2 * kNaRingBytes,
+                 kNaOffRad = 2 * kNaRingBytes + kNaRecBytes, kNaOffSkip = 2 * kNaRingBytes + 2 * kNaRecBytes;
+constexpr size_t kNaBytes = kNaOffSkip + PT_NOALLOC_MAX_SPP * sizeof(uint2);                // 16 MiB + 2 KiB
+constexpr int kMaxDevices = 64;
+}  // namespace
+static __device__ __align__(256) unsigned char scratch[kNaBytes];
+namespace
+{
+std::mutex g_scratchMutex;
+unsigned char *g_scratchPtr[kMaxDevices] = {};  // device address of `scratch` on each device, set by pt_create
 }  // namespace
 
 struct pt_ctx
@@ -80,6 +105,7 @@ struct pt_ctx
 	size_t pCap = 0;                        // records in pState / pRad
 	uint32_t lastLaunchFrames = 1;          // frames the most recent launch covered
 	int framesPerLaunch = 8;                // PT_FRAMES_PER_LAUNCH (16 buys +0.9 % at the headline config for 8.5 GB more)
+	unsigned char *naScratch = nullptr;     // this device's copy of `scratch` (pt_render_frames_noalloc)
 	size_t persistentBytes = 12ull << 30;   // budget for pState + pRad (PT_PERSISTENT_GB): 32 B per path per frame of a launch
 
 	int profiling = 0;
@@ -298,6 +324,24 @@ extern "C" pt_ctx *pt_create(int device)
 	}
 	pt_ctx *c = new pt_ctx();
 	c->device = device;
+	if (device < kMaxDevices)
+	{
+		// once per device, with that device current: the address of this device's copy of the scratch array
+		std::lock_guard<std::mutex> lock(g_scratchMutex);
+		if (!g_scratchPtr[device])
+		{
+			void *p = nullptr;
+			e = hipGetSymbolAddress(&p, HIP_SYMBOL(scratch));
+			if (e != hipSuccess || !p)
+			{
+				fail(nullptr, PT_EHIP, "pt_create: hipGetSymbolAddress(scratch): %s", hipGetErrorString(e));
+				delete c;
+				return nullptr;
+			}
+			g_scratchPtr[device] = static_cast<unsigned char *>(p);
+		}
+		c->naScratch = g_scratchPtr[device];
+	}
 	hipDeviceProp_t prop;
 	if (hipGetDeviceProperties(&prop, device) == hipSuccess) c->numCUs = prop.multiProcessorCount;
 	bool ok = hipStreamCreateWithFlags(&c->ownStream, hipStreamNonBlocking) == hipSuccess;
@@ -845,7 +889,10 @@ int ensurePersistent(pt_ctx *c, size_t records, bool *outOfMemory)
 }
 
 // `n` consecutive active frames (c->frame + 1 ...) on the persistent pipeline, several frames per launch.
-int renderPersistent(pt_ctx *c, int n)
+// noAlloc: pt_render_frames_noalloc -- the buffers this function otherwise allocates on demand are slices of the device's
+// scratch array, the grid is PT_NOALLOC_WAVES, no event is created and nothing is allocated or freed, on the device or
+// through the HIP runtime; the caller has checked the limits.
+int renderPersistent(pt_ctx *c, int n, bool noAlloc = false)
 {
 	const PtTile tile = c->tile.w ? c->tile : PtTile{ 0, 0, c->W, c->H };
 	const uint32_t WH = tile.w * tile.h;  // pixels a dispatch covers
@@ -854,6 +901,8 @@ int renderPersistent(pt_ctx *c, int n)
 	size_t perLaunch = (size_t)c->framesPerLaunch;
 	if (perLaunch * nPadded > 0xFFFFFF00ull) perLaunch = 0xFFFFFF00ull / nPadded;
 	size_t budget = c->persistentBytes;
+	if (noAlloc) budget = 2 * kNaRecBytes;
+	else
 	{
 		// never plan for more than half of what the device has left (plus what these buffers already hold)
 		size_t freeB = 0, totalB = 0;
@@ -866,9 +915,29 @@ int renderPersistent(pt_ctx *c, int n)
 	if (perLaunch * nPadded * 32 > budget) perLaunch = budget / (nPadded * 32);
 	if (perLaunch < 1) perLaunch = 1;
 	if (nPadded > 0xFFFFFF00ull) return fail(c, PT_EINVAL, "pt_render_frame: %zu paths per frame exceed 2^32", nPadded);
-	int rc = ensureLcgSkip(c);
-	if (rc) return rc;
 	hipStream_t s = c->stream;
+	int rc = PT_OK;
+	float4 *state = nullptr, *rad = nullptr, *ringO = nullptr, *ringD = nullptr;
+	const uint2 *lcgSkip = nullptr;
+	uint32_t waves = c->cfg.bounceWaves;
+	if (noAlloc)
+	{
+		unsigned char *base = c->naScratch;
+		ringO = reinterpret_cast<float4 *>(base + kNaOffRingO);
+		ringD = reinterpret_cast<float4 *>(base + kNaOffRingD);
+		state = reinterpret_cast<float4 *>(base + kNaOffState);
+		rad = reinterpret_cast<float4 *>(base + kNaOffRad);
+		// the table is rebuilt on the device for every call: another context on this GPU may have left its own behind
+		ptLaunchLcgSkip((uint32_t)c->spp, reinterpret_cast<uint2 *>(base + kNaOffSkip), s);
+		lcgSkip = reinterpret_cast<const uint2 *>(base + kNaOffSkip);
+		if (waves > PT_NOALLOC_WAVES) waves = PT_NOALLOC_WAVES;
+	}
+	else
+	{
+		rc = ensureLcgSkip(c);
+		if (rc) return rc;
+		lcgSkip = c->dLcgSkip;
+	}
 	PtSceneDev sc = sceneDev(c);
 	if (c->quadAccel.nQuads)
 	{
@@ -883,14 +952,21 @@ int renderPersistent(pt_ctx *c, int n)
 		// a multi-frame call sizes the buffers for full launches at once, so that a later, longer call (warm-up of 4 frames,
 		// then 64) does not reallocate 8 GB in the middle of a render; frame-by-frame callers keep a one-frame buffer
 		// (a second context on the GPU, or a 4K frame, may leave less room than the budget: halve and try again)
-		bool oom = false;
-		rc = ensurePersistent(c, nPadded * (n > 1 ? perLaunch : (size_t)batch), &oom);
-		if (rc && oom && perLaunch > 1 && n > 1)
+		if (!noAlloc)
 		{
-			perLaunch = (perLaunch + 1) / 2;
-			continue;
+			bool oom = false;
+			rc = ensurePersistent(c, nPadded * (n > 1 ? perLaunch : (size_t)batch), &oom);
+			if (rc && oom && perLaunch > 1 && n > 1)
+			{
+				perLaunch = (perLaunch + 1) / 2;
+				continue;
+			}
+			if (rc) return rc;
+			state = c->pState;
+			rad = c->pRad;
+			ringO = c->pRingO;
+			ringD = c->pRingD;
 		}
-		if (rc) return rc;
 		const uint32_t frame0 = (uint32_t)(c->frame + 1);
 		const uint32_t gframe0 = c->firstFrame + frame0 * c->frameStride;
 		uint32_t centre = 0xFFFFFFFFu;
@@ -898,7 +974,7 @@ int renderPersistent(pt_ctx *c, int n)
 			if (gframe0 + f * c->frameStride == 0) centre = f;
 		ptLaunchFrameBegin(c->counters, (uint32_t)0, 0, s);
 		hipEvent_t e0 = nullptr, e1 = nullptr, e2 = nullptr;
-		if (c->profiling & PT_PROFILE_KERNELS)
+		if ((c->profiling & PT_PROFILE_KERNELS) && !noAlloc)
 		{
 			if (!getEventTriple(c, e0, e1, e2)) e0 = e1 = e2 = nullptr;
 			else hipEventRecord(e0, s);
@@ -918,11 +994,11 @@ int renderPersistent(pt_ctx *c, int n)
 		pa.maxDepth = c->maxDepth;
 		pa.tmin = c->tmin;
 		pa.tmax = c->tmax;
-		pa.lcgSkip = c->dLcgSkip;
-		pa.ringO = c->pRingO;
-		pa.ringD = c->pRingD;
-		pa.state = c->pState;
-		pa.rad = c->pRad;
+		pa.lcgSkip = lcgSkip;
+		pa.ringO = ringO;
+		pa.ringD = ringD;
+		pa.state = state;
+		pa.rad = rad;
 		pa.itemHead = &c->counters->chunkHead[0];
 		pa.waveRays = c->cfg.waveRays;
 		pa.spill = c->cfg.spill;
@@ -931,9 +1007,9 @@ int renderPersistent(pt_ctx *c, int n)
 		pa.instances = c->dInstances;
 		pa.nInst = c->tlasDepth ? c->nInst : 0;
 		pa.tlasRoot = c->tlasRoot;
-		ptLaunchPaths(pa, c->cfg.bounceWaves, trav != nullptr, s);
+		ptLaunchPaths(pa, waves, trav != nullptr, s);
 		if (e1) hipEventRecord(e1, s);
-		ptLaunchAccumulateItems(c->pRad, tile, c->W, (uint32_t)c->spp, c->image, frame0, batch, c->accumMode, s);
+		ptLaunchAccumulateItems(rad, tile, c->W, (uint32_t)c->spp, c->image, frame0, batch, c->accumMode, s);
 		if (e2)
 		{
 			hipEventRecord(e2, s);
@@ -1040,6 +1116,38 @@ catch (const std::bad_alloc &)
 }
 
 extern "C" int pt_render_frame(pt_ctx *c) { return pt_render_frames(c, 1); }
+
+// pt_render_frames for callers that cannot allocate (include/pt_hip.h): same frames, same image, same counters, on the
+// device's fixed scratch array.  No hipMalloc / hipFree / event creation on this path, and no host allocation either.
+extern "C" int pt_render_frames_noalloc(pt_ctx *c, int n)
+{
+	int rc = checkReady(c, true);
+	if (rc) return rc;
+	if (n <= 0) return PT_OK;
+	if (!c->naScratch) return fail(c, PT_EHIP, "pt_render_frames_noalloc: no scratch on device %d", c->device);
+	if (c->pipeline != PT_PIPELINE_PERSISTENT || c->brute)
+		return fail(c, PT_EINVAL, "pt_render_frames_noalloc: PT_PIPELINE_PERSISTENT over a BVH only");
+	if ((uint32_t)c->spp > PT_NOALLOC_MAX_SPP)
+		return fail(c, PT_ELIMIT, "pt_render_frames_noalloc: spp_per_frame %d exceeds %u", c->spp, PT_NOALLOC_MAX_SPP);
+	const uint64_t pixels = c->tile.w ? (uint64_t)c->tile.w * c->tile.h : (uint64_t)c->W * c->H;
+	const uint64_t records = (pixels + PT_WAVE - 1) / PT_WAVE * PT_WAVE * (uint64_t)c->spp;
+	if (records > PT_NOALLOC_MAX_RECORDS)
+		return fail(c, PT_ELIMIT,
+		            "pt_render_frames_noalloc: %llu paths per frame (pixels rounded up to 64, times spp_per_frame) exceed the "
+		            "scratch array's %u; render tiles (pt_set_tile) or use pt_render_frames",
+		            (unsigned long long)records, PT_NOALLOC_MAX_RECORDS);
+	PT_HIP(c, hipSetDevice(c->device));
+	const long long next = (long long)c->frame + 1;
+	long long active = n;
+	if (c->maxFrames > 0) active = next >= c->maxFrames ? 0 : (c->maxFrames - next < n ? c->maxFrames - next : n);
+	if (active > 0)
+	{
+		rc = renderPersistent(c, (int)active, true);
+		if (rc) return rc;
+	}
+	c->frame += (int)(n - active);
+	return PT_OK;
+}
 
 extern "C" int pt_set_pipeline(pt_ctx *c, int mode)
 {

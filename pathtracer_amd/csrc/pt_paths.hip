@@ -628,6 +628,25 @@ __global__ void k_store_camera(PtCamera cam, PtCamera *dst)
 
 void ptLaunchStoreCamera(const PtCamera &cam, PtCamera *dst, hipStream_t s) { k_store_camera<<<1, 64, 0, s>>>(cam, dst); }
 
+namespace
+{
+// The host's table of ensureLcgSkip (pt_api.hip), entry by entry: u32 wrap-around products, so the same numbers.
+__global__ void k_lcg_skip(uint32_t spp, uint2 *dst)
+{
+	const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+	if (i >= spp) return;
+	uint32_t A = 1u, C = 0u;
+	for (uint32_t k = 0; k < 2u * i; ++k)
+	{
+		A = 1664525u * A;
+		C = 1664525u * C + 1013904223u;
+	}
+	dst[i] = make_uint2(A, C);
+}
+}  // namespace
+
+void ptLaunchLcgSkip(uint32_t spp, uint2 *dst, hipStream_t s) { k_lcg_skip<<<(spp + 63) / 64, 64, 0, s>>>(spp, dst); }
+
 void ptLaunchPaths(const PtPathsArgs &args, uint32_t waves, bool stats, hipStream_t s)
 {
 	// A/B knobs: PT_LDS_NODES_OFF = nodes from memory whatever the size, PT_LDS_PLANES_OFF = packed LDS copy only

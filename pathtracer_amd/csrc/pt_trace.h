@@ -93,6 +93,8 @@ struct PtPathsArgs
 };
 void ptLaunchPaths(const PtPathsArgs &args, uint32_t waves, bool stats, hipStream_t s);
 void ptLaunchStoreCamera(const PtCamera &cam, PtCamera *dst, hipStream_t s);
+// dst[i] = (A, C) with lcg^(2i)(s) = A * s + C, i < spp: the skip-ahead table of PtPathsArgs::lcgSkip, computed on the device
+void ptLaunchLcgSkip(uint32_t spp, uint2 *dst, hipStream_t s);
 void ptLaunchAccumulateItems(const float4 *rad, PtTile tile, uint32_t W, uint32_t spp, float4 *image, uint32_t lframe0,
                              uint32_t nFrames, int mode, hipStream_t s);
 void ptLaunchAccumulate(const PtQueues &q, PtTile tile, uint32_t W, uint32_t spp, float4 *image, uint32_t lframe, int mode,
