@@ -209,6 +209,19 @@ int pt_render_frame(pt_ctx *ctx);
 /* n consecutive pt_render_frame calls (convenience for the host loop, main.cpp:320-329). */
 int pt_render_frames(pt_ctx *ctx, int n);
 
+/* pt_render_frames for callers that cannot allocate.  NO COUNTERPART IN THE REFERENCE: it exists for code under HIP graph
+ * capture, tight serving loops and harnesses that forbid hipMalloc.  Same frames, same image, same frame counter and
+ * statistics as pt_render_frames(ctx, n) on PT_PIPELINE_PERSISTENT, but every buffer pt_render_frames allocates on demand
+ * (LCG skip-ahead table, per-path state and radiance, wave-private survivor rings) is a slice of a file-scope device array
+ * of 16 MiB + 2 KiB that each GPU the library runs on holds until the process ends; the call makes no hipMalloc / hipFree /
+ * event creation and no host allocation.  Scene, acceleration structure, camera and the image (pt_resize) are the caller's
+ * inputs and outputs as before.  Limits (PT_ELIMIT beyond them, nothing rendered): ceil(pixels of the image or tile / 64)
+ * * 64 * spp_per_frame <= 2^18 paths per frame (e.g. 512 x 512 x 1 spp, 256 x 256 x 4 spp; larger images tile by tile with
+ * pt_set_tile), spp_per_frame <= 256.  PT_PROFILE_KERNELS is ignored.  All contexts of one GPU share that GPU's array:
+ * calls that overlap on one GPU (two streams, two host threads) race; calls that follow each other, from any context,
+ * do not depend on what the previous one left behind. */
+int pt_render_frames_noalloc(pt_ctx *ctx, int n);
+
 /* VulkanRaytracing::resetFrame (VulkanRaytracing.cpp:910-913): frame = -1. */
 int pt_reset_accumulation(pt_ctx *ctx);
 /* m_pcRay.frame (VulkanRaytracing.h:35-38): -1 before the first dispatch. */

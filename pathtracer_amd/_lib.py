@@ -62,6 +62,7 @@ SYMBOLS = {
     "pt_set_pipeline": (_i, [_vp, _i]),
     "pt_render_frame": (_i, [_vp]),
     "pt_render_frames": (_i, [_vp, _i]),
+    "pt_render_frames_noalloc": (_i, [_vp, _i]),
     "pt_reset_accumulation": (_i, [_vp]),
     "pt_frame_index": (_i, [_vp]),
     "pt_read_image": (_i, [_vp, _vp]),

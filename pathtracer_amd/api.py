@@ -290,6 +290,11 @@ class HipRaytracing:
         """VulkanRaytracing::raytrace (VulkanRaytracing.cpp:868-901), `frames` times.  Asynchronous."""
         self._check(self._L.pt_render_frames(self._ctx, frames))
 
+    def raytraceNoAlloc(self, frames: int = 1):
+        """pt_render_frames_noalloc: the same frames on the GPU's fixed scratch array, without any allocation (limits in
+        include/pt_hip.h).  No counterpart in the reference."""
+        self._check(self._L.pt_render_frames_noalloc(self._ctx, frames))
+
     def updateFrame(self):
         raise NotImplementedError("updateFrame() is folded into raytrace(), as in VulkanRaytracing::raytrace")
 

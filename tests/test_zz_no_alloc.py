@@ -3,21 +3,12 @@ loops, harnesses that forbid hipMalloc).  It has no counterpart in the reference
 file-scope device scratch array of fixed size (16 MiB + 2 KiB per GPU): up to 2^18 paths per frame (pixels rounded up to
 64, times spp_per_frame) and 256 spp per frame.  Checked against pt_render_frames through the C ABI, bit for bit, on two
 calls in a row, the second with a smaller input; oversize inputs are refused with PT_ELIMIT."""
-import ctypes as C
-
 import numpy as np
 import pytest
 
 from conftest import bits
 
 pytestmark = pytest.mark.gpu
-
-
-@pytest.fixture(autouse=True)
-def _bind():
-    from pathtracer_amd import _lib
-    fn = _lib.lib().pt_render_frames_noalloc
-    fn.restype, fn.argtypes = C.c_int, [C.c_void_p, C.c_int]
 
 
 def render(pa, scene, W, H, spp, depth, frames, noalloc, seed=3, tile=None, ctx=None):
