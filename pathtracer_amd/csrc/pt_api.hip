@@ -347,9 +347,9 @@ extern "C" pt_ctx *pt_create(int device)
 	bool ok = hipStreamCreateWithFlags(&c->ownStream, hipStreamNonBlocking) == hipSuccess;
 	c->stream = c->ownStream;
 	ok = ok && hipMalloc(&c->counters, sizeof(PtFrameCounters)) == hipSuccess;
-	ok = ok && hipMalloc(&c->dStats, 8 * sizeof(unsigned long long)) == hipSuccess;
+	ok = ok && hipMalloc(&c->dStats, 32 * sizeof(unsigned long long)) == hipSuccess;
 	ok = ok && hipMalloc(&c->dCam, sizeof(PtCamera)) == hipSuccess;
-	ok = ok && hipMemset(c->dStats, 0, 8 * sizeof(unsigned long long)) == hipSuccess;
+	ok = ok && hipMemset(c->dStats, 0, 32 * sizeof(unsigned long long)) == hipSuccess;
 	// persistent grid: blocks of 256 threads per CU (tuning knob PT_BLOCKS_PER_CU, default 4)
 	int blocksPerCU = 4;
 	if (const char *e = getenv("PT_BLOCKS_PER_CU"))
@@ -946,6 +946,12 @@ int renderPersistent(pt_ctx *c, int n, bool noAlloc = false)
 		sc.nQuads = c->quadAccel.nQuads;
 	}
 	unsigned long long *trav = (c->profiling & PT_PROFILE_TRAVERSAL) ? c->dStats + 2 : nullptr;
+#ifdef PT_PATHS_TIMING
+	const bool statsKernel = trav != nullptr;
+	trav = c->dStats + 2;  // tuning build: the section timers live behind the traversal counters
+#else
+	const bool statsKernel = trav != nullptr;
+#endif
 	while (n > 0)
 	{
 		uint32_t batch = (uint32_t)((size_t)n < perLaunch ? (size_t)n : perLaunch);
@@ -1007,7 +1013,7 @@ int renderPersistent(pt_ctx *c, int n, bool noAlloc = false)
 		pa.instances = c->dInstances;
 		pa.nInst = c->tlasDepth ? c->nInst : 0;
 		pa.tlasRoot = c->tlasRoot;
-		ptLaunchPaths(pa, waves, trav != nullptr, s);
+		ptLaunchPaths(pa, waves, statsKernel, s);
 		if (e1) hipEventRecord(e1, s);
 		ptLaunchAccumulateItems(rad, tile, c->W, (uint32_t)c->spp, c->image, frame0, batch, c->accumMode, s);
 		if (e2)
@@ -1386,6 +1392,18 @@ extern "C" int pt_get_stats(pt_ctx *c, PtStats *out)
 	out->trav_leaf_visits = h[5];
 	out->trav_node_steps = h[6];
 	out->trav_leaf_steps = h[7];
+#ifdef PT_PATHS_TIMING
+	{
+		unsigned long long t[8] = {};
+		hipMemcpy(t, c->dStats + 8, sizeof(t), hipMemcpyDeviceToHost);
+		double sum = 0;
+		for (unsigned long long x : t) sum += (double)x;
+		static const char *names[8] = { "loop", "retire", "flush", "ring", "gen", "take", "node", "leaf" };
+		fprintf(stderr, "[k_paths section shares]");
+		for (int i = 0; i < 8; ++i) fprintf(stderr, " %s %.1f%%", names[i], sum > 0 ? 100.0 * (double)t[i] / sum : 0.0);
+		fprintf(stderr, "  (%.3g wave-cycles)\n", sum);
+	}
+#endif
 	return PT_OK;
 }
 
@@ -1395,7 +1413,7 @@ extern "C" int pt_reset_stats(pt_ctx *c)
 	PT_HIP(c, hipSetDevice(c->device));
 	PT_HIP(c, hipStreamSynchronize(c->stream));
 	drainEvents(c);
-	PT_HIP(c, hipMemset(c->dStats, 0, 8 * sizeof(unsigned long long)));
+	PT_HIP(c, hipMemset(c->dStats, 0, 32 * sizeof(unsigned long long)));
 	c->extendMs = c->shadeMs = 0.0;
 	c->extendLaunches = c->shadeLaunches = c->framesRendered = 0;
 	return PT_OK;

@@ -13,6 +13,7 @@
 #include "pt_build.h"
 
 #include <float.h>
+#include <stdlib.h>
 #include <string.h>
 
 namespace
@@ -175,27 +176,30 @@ __global__ void __launch_bounds__(kBlock) k_morton(const float4 *triLo, const fl
 }
 
 // ------------------------------------------------------------------- radix sort ----
-// LSD, 8 bits per pass.  A block owns one tile of kTile consecutive keys; wave w of the block
-// owns the w-th quarter of the tile and walks it in rounds of 64 consecutive keys, so that
-// (wave, round, lane) order == input order and the scatter is stable.
+// LSD, kRadixBits per pass.  A block owns one tile of kTile consecutive keys; wave w of the block owns the
+// w-th quarter of the tile and walks it in rounds of 64 consecutive keys, so that (wave, round, lane) order == input
+// order and the scatter is stable.
 constexpr int kItems = 8;
 constexpr int kTile = kBlock * kItems;
+constexpr int kRadixBits = 8;   // measured at 100 M keys: 10-bit digits (3 passes) scatter 2 keys per digit and tile -- 1.85 ms a pass against 1.0
+constexpr int kRadixBins = 1 << kRadixBits;
+constexpr int kSortBits = 32;  // bits of the key that are sorted (30-bit Morton codes: four 8-bit passes)
 
 __global__ void __launch_bounds__(kBlock) k_radix_hist(const uint32_t *keys, uint32_t n, int shift, uint32_t *hist,
                                                        uint32_t nBlocks)
 {
-	__shared__ uint32_t bins[256];
-	bins[threadIdx.x] = 0;
+	__shared__ uint32_t bins[kRadixBins];
+	for (int i = threadIdx.x; i < kRadixBins; i += kBlock) bins[i] = 0;
 	__syncthreads();
 	size_t base = (size_t)blockIdx.x * kTile;
 #pragma unroll
 	for (int r = 0; r < kItems; ++r)
 	{
 		size_t i = base + r * kBlock + threadIdx.x;
-		if (i < n) atomicAdd(&bins[(keys[i] >> shift) & 255u], 1u);
+		if (i < n) atomicAdd(&bins[(keys[i] >> shift) & (uint32_t)(kRadixBins - 1)], 1u);
 	}
 	__syncthreads();
-	hist[(size_t)threadIdx.x * nBlocks + blockIdx.x] = bins[threadIdx.x];
+	for (int i = threadIdx.x; i < kRadixBins; i += kBlock) hist[(size_t)i * nBlocks + blockIdx.x] = bins[i];
 }
 
 // ------------------------------------------------------------------------- scan ----
@@ -309,10 +313,12 @@ __global__ void __launch_bounds__(kBlock) k_radix_scatter(const uint32_t *keysIn
                                                           const uint32_t *histScanned, uint32_t nBlocks)
 {
 	constexpr int kWaves = kBlock / PT_WAVE;
-	__shared__ uint32_t waveCount[kWaves][256];
-	__shared__ uint32_t digitBase[256];
+	constexpr uint32_t kMask = (uint32_t)(kRadixBins - 1);
+	__shared__ uint32_t waveCount[kWaves][kRadixBins];
+	__shared__ uint32_t digitBase[kRadixBins], tileStart[kRadixBins], sScan[kBlock / PT_WAVE];
+	__shared__ uint32_t sKey[kTile], sVal[kTile];
 	const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-	for (int i = threadIdx.x; i < kWaves * 256; i += kBlock) (&waveCount[0][0])[i] = 0;
+	for (int i = threadIdx.x; i < kWaves * kRadixBins; i += kBlock) (&waveCount[0][0])[i] = 0;
 	__syncthreads();
 
 	uint32_t key[kItems], val[kItems], rank[kItems];
@@ -325,12 +331,12 @@ __global__ void __launch_bounds__(kBlock) k_radix_scatter(const uint32_t *keysIn
 		bool valid = i < n;
 		key[r] = valid ? keysIn[i] : 0xFFFFFFFFu;
 		val[r] = valid ? valsIn[i] : 0u;
-		uint32_t digit = (key[r] >> shift) & 255u;
+		uint32_t digit = (key[r] >> shift) & kMask;
 		// lanes of this round holding the same digit (and the same validity)
 		unsigned long long peers = __ballot(valid);
 		if (!valid) peers = ~peers;
 #pragma unroll
-		for (int b = 0; b < 8; ++b)
+		for (int b = 0; b < kRadixBits; ++b)
 		{
 			unsigned long long m = __ballot((digit >> b) & 1u);
 			peers &= ((digit >> b) & 1u) ? m : ~m;
@@ -341,17 +347,27 @@ __global__ void __launch_bounds__(kBlock) k_radix_scatter(const uint32_t *keysIn
 		if (valid && (peers & lanesBelow) == 0) waveCount[wave][digit] = before + __popcll(peers);
 	}
 	__syncthreads();
+	// per digit: exclusive scan across the waves of the block, and the digit's total in this tile
+	static_assert(kRadixBins == kBlock, "one digit per thread below");
+	uint32_t digitTotal;
 	{
-		// exclusive scan across the waves of the block for digit = threadIdx.x
+		const int d = threadIdx.x;
 		uint32_t run = 0;
 		for (int w = 0; w < kWaves; ++w)
 		{
-			uint32_t c = waveCount[w][threadIdx.x];
-			waveCount[w][threadIdx.x] = run;
+			uint32_t c = waveCount[w][d];
+			waveCount[w][d] = run;
 			run += c;
 		}
-		digitBase[threadIdx.x] = histScanned[(size_t)threadIdx.x * nBlocks + blockIdx.x];
+		digitTotal = run;
+		digitBase[d] = histScanned[(size_t)d * nBlocks + blockIdx.x];
 	}
+	// Position of every key inside the tile once the tile is sorted by digit (stable): the keys go through LDS in that
+	// order, so that consecutive lanes then store consecutive addresses of one digit's run -- a wave store touches ~9 runs
+	// instead of 64 single words (measured at 100 M keys: 1.0 ms -> see DESIGN.md 5.1 per pass).
+	uint32_t tileTotal;
+	const uint32_t start = blockExclusiveScan(digitTotal, sScan, tileTotal);
+	tileStart[threadIdx.x] = start;
 	__syncthreads();
 #pragma unroll
 	for (int r = 0; r < kItems; ++r)
@@ -359,10 +375,23 @@ __global__ void __launch_bounds__(kBlock) k_radix_scatter(const uint32_t *keysIn
 		size_t i = waveBase + r * PT_WAVE + lane;
 		if (i < n)
 		{
-			uint32_t digit = (key[r] >> shift) & 255u;
-			uint32_t dst = digitBase[digit] + waveCount[wave][digit] + rank[r];
-			keysOut[dst] = key[r];
-			valsOut[dst] = val[r];
+			uint32_t digit = (key[r] >> shift) & kMask;
+			uint32_t pos = tileStart[digit] + waveCount[wave][digit] + rank[r];
+			sKey[pos] = key[r];
+			sVal[pos] = val[r];
+		}
+	}
+	__syncthreads();
+#pragma unroll
+	for (int r = 0; r < kItems; ++r)
+	{
+		const uint32_t pos = r * kBlock + threadIdx.x;
+		if (pos < tileTotal)
+		{
+			const uint32_t k = sKey[pos], digit = (k >> shift) & kMask;
+			const uint32_t dst = digitBase[digit] + (pos - tileStart[digit]);
+			keysOut[dst] = k;
+			valsOut[dst] = sVal[pos];
 		}
 	}
 }
@@ -377,8 +406,12 @@ __device__ __forceinline__ int lbvhDelta(const uint32_t *keys, int n, int i, int
 	return __clz(a ^ b);
 }
 
-__global__ void __launch_bounds__(kBlock) k_lbvh_topology(const uint32_t *keys, int n, int2 *children, int *parent,
-                                                          int2 *range)
+// One 16-byte record per internal node: (left child, right child, parent, other end of the node's range of sorted positions).
+// A Karras node i sits at one end of its range, so range = [min(i, j), max(i, j)] and the subtree holds |j - i| + 1 leaves:
+// the refit walk reads ONE record per level (children, range for the LDS test, next parent) where three arrays cost it
+// three dependent loads.  The parent word of record c is written by c's parent's thread, the other three by c's own:
+// separate stores to separate words, no conflict.  leafParent[k] = parent of the leaf at sorted position k.
+__global__ void __launch_bounds__(kBlock) k_lbvh_topology(const uint32_t *keys, int n, int4 *topo, int *leafParent)
 {
 	int i = blockIdx.x * kBlock + threadIdx.x;
 	if (i >= n - 1) return;
@@ -402,12 +435,43 @@ __global__ void __launch_bounds__(kBlock) k_lbvh_topology(const uint32_t *keys, 
 	int first = i < j ? i : j, last = i < j ? j : i;
 	int left = (first == gamma) ? (n - 1) + gamma : gamma;
 	int right = (last == gamma + 1) ? (n - 1) + gamma + 1 : gamma + 1;
-	children[i] = make_int2(left, right);
-	range[i] = make_int2(first, last);
-	parent[left] = i;
-	parent[right] = i;
-	if (i == 0) parent[0] = -1;
+	int *rec = reinterpret_cast<int *>(topo + i);
+	*reinterpret_cast<int2 *>(rec) = make_int2(left, right);
+	rec[3] = j;
+	if (left >= n - 1) leafParent[left - (n - 1)] = i;
+	else reinterpret_cast<int *>(topo + left)[2] = i;
+	if (right >= n - 1) leafParent[right - (n - 1)] = i;
+	else reinterpret_cast<int *>(topo + right)[2] = i;
+	if (i == 0) rec[2] = -1;
 }
+
+// The BVH2 as the collapse sees it: LBVH = the topology records (children, leaf count and first sorted position all come
+// out of one record), PLOC = children + subtree leaf counts in two arrays.  Leaf for sorted position k = node (n-1) + k.
+struct Bvh2View
+{
+	const int4 *topo;          // LBVH, else nullptr
+	const int2 *children;      // PLOC
+	const uint32_t *subCount;  // PLOC
+	int n;
+	__device__ __forceinline__ int2 kids(int nd) const
+	{
+		return topo ? *reinterpret_cast<const int2 *>(topo + nd) : children[nd];
+	}
+	__device__ __forceinline__ uint32_t count(int nd) const
+	{
+		if (!topo) return subCount[nd];
+		if (nd >= n - 1) return 1u;
+		const int j = reinterpret_cast<const int *>(topo + nd)[3];
+		return (uint32_t)(j > nd ? j - nd : nd - j) + 1u;
+	}
+	// LBVH only: first sorted position of the subtree
+	__device__ __forceinline__ uint32_t first(int nd) const
+	{
+		if (nd >= n - 1) return (uint32_t)(nd - (n - 1));
+		const int j = reinterpret_cast<const int *>(topo + nd)[3];
+		return (uint32_t)(j < nd ? j : nd);
+	}
+};
 
 // ------------------------------------------------------------------------- refit ----
 // boxes: 2 float4 per BVH2 node: (lo.xyz, -) (hi.xyz, -).  Boxes cross CUs inside this launch,
@@ -442,9 +506,13 @@ __device__ __forceinline__ void loadBox(const float *src, float lo[3], float hi[
 //     (s_waitcnt vmcnt(0)), then an agent-scope atomic counts the arrival and the sibling's box is read with
 //     agent-scope loads (MI355X_MICROARCH.md, cross-CU hand-off inside a launch).
 // Every node's box is also written to `boxes` for the collapse kernel.
-__global__ void __launch_bounds__(kBlock) k_refit(const float4 *triLo, const float4 *triHi, const uint32_t *sortedPrim,
-                                                  int n, const int2 *children, const int *parent, const int2 *range,
-                                                  const int *bounds, float *boxes, unsigned int *arrive, float padScale)
+// The leaf's own box: triangles -- from the gathered 48-byte position record triPos[prim], the SAME gather the leaf-ordered
+// triangle array needs (LBVH: leaf order is the sorted order), so the thread writes its three rotated PtTri48 records here
+// too and the primitive boxes are never gathered; boxes (top level) -- from triLo/triHi as given.
+__global__ void __launch_bounds__(kBlock) k_refit(const float4 *triPos, const float4 *triLo, const float4 *triHi,
+                                                  const uint32_t *sortedPrim, int n, const int4 *topo, const int *leafParent,
+                                                  const int *bounds, float *boxes, unsigned int *arrive, float padScale,
+                                                  PtTri48 *tris)
 {
 	__shared__ float sBox[6][2 * kBlock];  // slot: internal node i -> i - base, leaf k -> kBlock + k - base
 	__shared__ unsigned int sArrive[kBlock];
@@ -453,25 +521,63 @@ __global__ void __launch_bounds__(kBlock) k_refit(const float4 *triLo, const flo
 	__syncthreads();
 	if (k >= n) return;
 	const float pad = __uint_as_float((unsigned int)bounds[6]) * padScale;  // 2^-18 * max|coord| for triangles
-	uint32_t prim = sortedPrim[k];
-	float4 l4 = triLo[2 * (size_t)prim], h4 = triHi[2 * (size_t)prim];
-	float lo[3] = { l4.x - pad, l4.y - pad, l4.z - pad }, hi[3] = { h4.x + pad, h4.y + pad, h4.z + pad };
+	const uint32_t prim = sortedPrim[k];
 	int cur = (n - 1) + k;
-	int p = parent[cur];
+	int p = leafParent[k];
+	float lo[3], hi[3];
+	if (triPos)
+	{
+		const float4 r0 = triPos[3 * (size_t)prim + 0], r1 = triPos[3 * (size_t)prim + 1], r2 = triPos[3 * (size_t)prim + 2];
+		const float q[3][3] = { { r0.x, r0.y, r0.z }, { r0.w, r1.x, r1.y }, { r1.z, r1.w, r2.x } };
+#pragma unroll
+		for (int r = 0; r < 3; ++r)
+		{
+			const int x = (r + 1) % 3, y = (r + 2) % 3, z = r;
+			float4 *dst = reinterpret_cast<float4 *>(tris + (size_t)r * n + k);
+			dst[0] = make_float4(q[0][x], q[0][y], q[0][z], q[1][x]);
+			dst[1] = make_float4(q[1][y], q[1][z], q[2][x], q[2][y]);
+			dst[2] = make_float4(q[2][z], __uint_as_float(prim), 0.0f, 0.0f);
+		}
+		// exactly k_tri_setup's box of the primitive (same compares in the same order)
+#pragma unroll
+		for (int a = 0; a < 3; ++a)
+		{
+			float l = INFINITY, h = -INFINITY;
+#pragma unroll
+			for (int j = 0; j < 3; ++j)
+			{
+				const float c = q[j][a];
+				if (c < l) l = c;
+				if (c > h) h = c;
+			}
+			lo[a] = l - pad;
+			hi[a] = h + pad;
+		}
+	}
+	else
+	{
+		const float4 l4 = triLo[2 * (size_t)prim], h4 = triHi[2 * (size_t)prim];
+		lo[0] = l4.x - pad; lo[1] = l4.y - pad; lo[2] = l4.z - pad;
+		hi[0] = h4.x + pad; hi[1] = h4.y + pad; hi[2] = h4.z + pad;
+	}
 	bool local = true;
 	for (;;)
 	{
+		// Every lane that arrives, first or second, stores the node's box here: consecutive lanes write consecutive 32-byte
+		// boxes, whole lines at a time.  (Measured at 100 M triangles, this kernel 12.8 ms: the same stores split between the
+		// two arrivals 31 ms; the record requested a level ahead and LDS-only fences, so that no wait covers a store, 22 ms --
+		// the full waits pace the stores, and the memory system does better paced.)
 		float4 *dst = reinterpret_cast<float4 *>(boxes + 8 * (size_t)cur);
 		dst[0] = make_float4(lo[0], lo[1], lo[2], 0.0f);
 		dst[1] = make_float4(hi[0], hi[1], hi[2], 0.0f);
 		if (p < 0) return;  // cur is the root
+		const int4 t = topo[p];  // children, parent of p, other end of p's range: one load per level
 		if (local)
 		{
-			const int2 r = range[p];
-			local = r.x >= base && r.y < base + kBlock;
+			const int first = t.w < p ? t.w : p, last = t.w < p ? p : t.w;
+			local = first >= base && last < base + kBlock;
 		}
-		const int2 ch = children[p];
-		const int sib = ch.x == cur ? ch.y : ch.x;
+		const int sib = t.x == cur ? t.y : t.x;
 		if (local)
 		{
 			const int slot = cur >= n - 1 ? kBlock + (cur - (n - 1) - base) : cur - base;
@@ -508,7 +614,7 @@ __global__ void __launch_bounds__(kBlock) k_refit(const float4 *triLo, const flo
 			}
 		}
 		cur = p;
-		p = parent[p];
+		p = t.z;
 	}
 }
 
@@ -528,15 +634,27 @@ __device__ __forceinline__ float halfArea(const float *box)
 // One thread per wide node of the level.  Children that stay inner nodes become the tasks of the next level; their
 // node ids are childBase + position in that queue (breadth-first numbering), so ONE block-aggregated atomic hands
 // out both (a per-child atomic on a single counter serialises: 4 ms of a 20 M-triangle build).
+// The level loop runs on the device: levelCount[L] = wide nodes of level L (levelCount[0] = 1, the root), written by
+// level L - 1's launch; the host enqueues kMaxLevels launches back to back and reads the counts once at the end (a
+// read-back per level cost ~0.1 ms each, 16 of them at 100 M triangles).  Empty levels return at once.
+constexpr int kMaxLevels = 32;  // trees deeper than the traversal stack allows (28 levels) are rejected by the caller anyway
+
 __global__ void __launch_bounds__(kBlock)
-    k_collapse_level(const CollapseTask *tasksIn, uint32_t nIn, CollapseTask *tasksOut, uint32_t *nOut, int n,
-                     const int2 *children, const int2 *range, const uint32_t *subCount, const float *boxes,
-                     const uint32_t *sortedPrim, bool boxMode, uint32_t *leafPrim, PtNode4 *nodes, uint32_t childBase,
+    k_collapse_level(const CollapseTask *tasksIn, CollapseTask *tasksOut, uint32_t *levelCount, int level, Bvh2View bvh,
+                     const float *boxes, const uint32_t *sortedPrim, bool boxMode, uint32_t *leafPrim, PtNode4 *nodes,
                      uint32_t *triCount, int leafMax, uint32_t nodeBase)
 {
 	__shared__ unsigned long long sWave[kBlock / PT_WAVE];
 	__shared__ uint32_t sBase[2];
-	const uint32_t ti = blockIdx.x * kBlock + threadIdx.x;
+	const int n = bvh.n;
+	const uint32_t nIn = levelCount[level];
+	if (nIn == 0) return;
+	uint32_t childBase = 0;  // wide nodes of the levels 0 .. level = id of the first node of the next level
+	for (int l = 0; l <= level; ++l) childBase += levelCount[l];
+	uint32_t *nOut = levelCount + level + 1;
+	for (uint32_t t0 = blockIdx.x * kBlock; t0 < nIn; t0 += gridDim.x * kBlock)
+	{
+	const uint32_t ti = t0 + threadIdx.x;
 	const bool active = ti < nIn;
 	CollapseTask task = { 0, 0u };
 	int slot[4] = { 0, 0, 0, 0 };
@@ -545,7 +663,7 @@ __global__ void __launch_bounds__(kBlock)
 	if (active)
 	{
 		task = tasksIn[ti];
-		const uint32_t rootCount = subCount[task.bvh2];
+		const uint32_t rootCount = bvh.count(task.bvh2);
 		if ((int)rootCount <= leafMax)
 		{
 			slot[0] = task.bvh2;  // whole subtree is one leaf child
@@ -558,7 +676,7 @@ __global__ void __launch_bounds__(kBlock)
 			// scratch memory): "write entry s" is a select over the four entries
 			float area[4] = { -1.0f, -1.0f, -1.0f, -1.0f };
 			auto put = [&](int s, int nd) {
-				const uint32_t c = subCount[nd];
+				const uint32_t c = bvh.count(nd);
 				const float ar = (int)c <= leafMax ? -1.0f : halfArea(boxes + 8 * (size_t)nd);  // leaf children are never opened
 #pragma unroll
 				for (int k = 0; k < 4; ++k)
@@ -569,7 +687,7 @@ __global__ void __launch_bounds__(kBlock)
 						area[k] = ar;
 					}
 			};
-			int2 ch = children[task.bvh2];
+			int2 ch = bvh.kids(task.bvh2);
 			put(0, ch.x);
 			put(1, ch.y);
 			nSlots = 2;
@@ -588,7 +706,7 @@ __global__ void __launch_bounds__(kBlock)
 					}
 				if (best >= 0)  // otherwise every child is a leaf: nothing to open, in this round or the next
 				{
-					int2 ch2 = children[bestNode];
+					int2 ch2 = bvh.kids(bestNode);
 					put(best, ch2.x);
 					put(nSlots++, ch2.y);
 				}
@@ -612,7 +730,7 @@ __global__ void __launch_bounds__(kBlock)
 		sBase[1] = (leafPrim && (uint32_t)(total >> 32)) ? atomicAdd(triCount, (uint32_t)(total >> 32)) : 0u;
 	}
 	__syncthreads();
-	if (!active) return;
+	if (!active) continue;
 	uint32_t q = sBase[0] + (uint32_t)ex, triBase = sBase[1] + (uint32_t)(ex >> 32);
 
 	// node frame: origin = min corner, power-of-two scale per axis covering the extent in 255 steps
@@ -696,8 +814,7 @@ __global__ void __launch_bounds__(kBlock)
 				// Box mode (leafMax == 1): the leaf reference is the primitive (instance) index itself.
 				// LBVH: a subtree covers consecutive sorted positions and the triangle array is in sorted order,
 				// so the leaf is (first position, count) -- nothing to gather, nothing to allocate.
-				const int nd = slot[s];
-				const uint32_t first = nd >= n - 1 ? (uint32_t)(nd - (n - 1)) : (uint32_t)range[nd].x;
+				const uint32_t first = bvh.first(slot[s]);
 				node.child[s] = boxMode ? (PT_LEAF_FLAG | sortedPrim[first]) : (PT_LEAF_FLAG | ((uint32_t)(c - 1) << 28) | first);
 				continue;
 			}
@@ -710,7 +827,7 @@ __global__ void __launch_bounds__(kBlock)
 				if (nd >= n - 1) leafPrim[triBase + np++] = sortedPrim[nd - (n - 1)];
 				else
 				{
-					int2 ch = children[nd];
+					int2 ch = bvh.kids(nd);
 					dfs[dsp++] = ch.y;
 					dfs[dsp++] = ch.x;
 				}
@@ -727,6 +844,7 @@ __global__ void __launch_bounds__(kBlock)
 		}
 	}
 	nodes[task.out] = node;
+	}
 }
 
 
@@ -751,14 +869,6 @@ __global__ void __launch_bounds__(kBlock) k_write_tris(const uint32_t *leafPrim,
 		dst[1] = make_float4(b[y], b[z], c[x], c[y]);
 		dst[2] = make_float4(c[z], __uint_as_float(prim), 0.0f, 0.0f);
 	}
-}
-
-// subtree leaf counts of the LBVH (internal node i covers sorted positions range[i].x .. range[i].y)
-__global__ void __launch_bounds__(kBlock) k_lbvh_counts(const int2 *range, int n, uint32_t *subCount)
-{
-	int i = blockIdx.x * kBlock + threadIdx.x;
-	if (i < n - 1) subCount[i] = (uint32_t)(range[i].y - range[i].x + 1);
-	if (i < n) subCount[(n - 1) + i] = 1u;
 }
 
 // ----------------------------------------------------------------------------- PLOC ----
@@ -913,7 +1023,7 @@ hipError_t ptBuildBvh4(const PtBuildInput &in, PtBuildOutput &out, hipStream_t s
 	// ---- scratch: ONE allocation carved into 256-byte aligned pieces (hipMalloc/hipFree of two dozen multi-GB
 	// buffers cost more than the build itself), freed on exit ----
 	const uint32_t nSortBlocks = divUp(n, kTile);
-	const size_t histLen = (size_t)256 * nSortBlocks;
+	const size_t histLen = (size_t)kRadixBins * nSortBlocks;
 	const size_t nNodes2 = 2 * (size_t)n - 1;
 	const uint32_t plocBlocks = divUp(n, kBlock);
 	size_t arenaBytes = 0;
@@ -929,14 +1039,16 @@ hipError_t ptBuildBvh4(const PtBuildInput &in, PtBuildOutput &out, hipStream_t s
 	const size_t oKeysA = reserve(4 * (size_t)n), oKeysB = reserve(4 * (size_t)n), oValsA = reserve(4 * (size_t)n),
 	             oValsB = reserve(4 * (size_t)n);
 	const size_t oHist = reserve(4 * histLen), oScan = reserve(4 * scanScratchLen(histLen));
-	const size_t oChildren = reserve(sizeof(int2) * n), oRange = reserve(sizeof(int2) * n);
-	const size_t oParent = reserve(sizeof(int) * nNodes2), oBoxes = reserve(sizeof(float) * 8 * nNodes2);
-	const size_t oArrive = reserve(sizeof(unsigned int) * n), oSubCount = reserve(sizeof(uint32_t) * nNodes2);
+	// LBVH: one 16-byte topology record per internal node + the leaves' parents; PLOC: children + subtree leaf counts
+	const size_t oTopo = reserve(ploc ? 0 : sizeof(int4) * n), oLeafParent = reserve(ploc ? 0 : sizeof(int) * n);
+	const size_t oChildren = reserve(ploc ? sizeof(int2) * n : 0), oSubCount = reserve(ploc ? sizeof(uint32_t) * nNodes2 : 0);
+	const size_t oBoxes = reserve(sizeof(float) * 8 * nNodes2);
+	const size_t oArrive = reserve(ploc ? 0 : sizeof(unsigned int) * n);
 	const size_t oClusterA = reserve(ploc ? 4 * (size_t)n : 0), oClusterB = reserve(ploc ? 4 * (size_t)n : 0),
 	             oNearest = reserve(ploc ? 4 * (size_t)n : 0), oLeafPrim = reserve(ploc && !boxMode ? 4 * (size_t)n : 0);
 	const size_t oPlocSums = reserve(ploc ? 8 * (((size_t)plocBlocks + 63) / 64 * 64 + scanScratchLen(plocBlocks)) : 0);
 	const size_t oPlocTotal = reserve(64);
-	const size_t oTaskA = reserve(sizeof(CollapseTask) * n), oTaskB = reserve(sizeof(CollapseTask) * n), oCounters = reserve(64);
+	const size_t oTaskA = reserve(sizeof(CollapseTask) * n), oTaskB = reserve(sizeof(CollapseTask) * n), oCounters = reserve(256);
 	char *arena = nullptr;
 	hipError_t err = hipMalloc(&arena, arenaBytes);
 #define TRY(x)                      \
@@ -946,8 +1058,9 @@ hipError_t ptBuildBvh4(const PtBuildInput &in, PtBuildOutput &out, hipStream_t s
 	int *bounds = AT(int, oBounds);
 	uint32_t *keysA = AT(uint32_t, oKeysA), *keysB = AT(uint32_t, oKeysB), *valsA = AT(uint32_t, oValsA),
 	         *valsB = AT(uint32_t, oValsB), *hist = AT(uint32_t, oHist), *scanScratch = AT(uint32_t, oScan);
-	int2 *children = AT(int2, oChildren), *range = AT(int2, oRange);
-	int *parent = AT(int, oParent);
+	int4 *topo = AT(int4, oTopo);
+	int *leafParent = AT(int, oLeafParent);
+	int2 *children = AT(int2, oChildren);
 	float *boxes = AT(float, oBoxes);
 	unsigned int *arrive = AT(unsigned int, oArrive);
 	uint32_t *subCount = AT(uint32_t, oSubCount), *clusterA = AT(uint32_t, oClusterA), *clusterB = AT(uint32_t, oClusterB),
@@ -955,7 +1068,7 @@ hipError_t ptBuildBvh4(const PtBuildInput &in, PtBuildOutput &out, hipStream_t s
 	unsigned long long *plocSums = AT(unsigned long long, oPlocSums);
 	uint32_t *plocTotal = AT(uint32_t, oPlocTotal);  // one packed (keep, merge) pair = two uint32
 	CollapseTask *taskA = AT(CollapseTask, oTaskA), *taskB = AT(CollapseTask, oTaskB);
-	uint32_t *counters = AT(uint32_t, oCounters);  // [0]=nodeCount [1]=triCount [2]=queue count
+	uint32_t *counters = AT(uint32_t, oCounters);  // [1] = triangle slots handed out (PLOC); [8 + L] = wide nodes of level L
 #undef AT
 	// outputs
 	PtNode4 *nodes = nullptr;
@@ -977,7 +1090,7 @@ hipError_t ptBuildBvh4(const PtBuildInput &in, PtBuildOutput &out, hipStream_t s
 			                                                                       bounds, triPos);
 		k_morton<<<gridTris, kBlock, 0, stream>>>(triLo, triHi, n, bounds, codes, keysA, valsA);
 		uint32_t *kin = keysA, *kout = keysB, *vin = valsA, *vout = valsB;
-		for (int shift = 0; shift < 32; shift += 8)
+		for (int shift = 0; shift < kSortBits; shift += kRadixBits)
 		{
 			k_radix_hist<<<nSortBlocks, kBlock, 0, stream>>>(kin, n, shift, hist, nSortBlocks);
 			scanExclusive<uint32_t>(hist, histLen, scanScratch, nullptr, stream);
@@ -989,19 +1102,19 @@ hipError_t ptBuildBvh4(const PtBuildInput &in, PtBuildOutput &out, hipStream_t s
 			vin = vout;
 			vout = t;
 		}
-		// after an even number of passes the sorted data is back in (keysA, valsA)
+		// (kin, vin) hold the sorted data whatever the number of passes
 		err = hipMemcpyAsync(order, vin, 4 * (size_t)n, hipMemcpyDeviceToDevice, stream);
 		int rootNode = 0;  // LBVH: internal node 0 (or the only leaf, index 0, when n == 1)
 		if (err == hipSuccess && !ploc)
 		{
 			err = hipMemsetAsync(arrive, 0, sizeof(unsigned int) * n, stream);
-			if (n > 1) k_lbvh_topology<<<divUp(n - 1, kBlock), kBlock, 0, stream>>>(kin, (int)n, children, parent, range);
-			else TRY(hipMemsetAsync(parent, 0xFF, sizeof(int), stream));  // single leaf: parent = -1
-			k_refit<<<gridTris, kBlock, 0, stream>>>(triLo, triHi, vin, (int)n, children, parent, range, bounds, boxes,
-			                                         arrive, padScale);
-			k_lbvh_counts<<<gridTris, kBlock, 0, stream>>>(range, (int)n, subCount);
-			// the triangle array is in sorted order: independent of the collapse
-			if (!boxMode) k_write_tris<<<gridTris, kBlock, 0, stream>>>(vin, n, triPos, tris);
+			if (n > 1) k_lbvh_topology<<<divUp(n - 1, kBlock), kBlock, 0, stream>>>(kin, (int)n, topo, leafParent);
+			else TRY(hipMemsetAsync(leafParent, 0xFF, sizeof(int), stream));  // single leaf: parent = -1
+			// leaf boxes, the bottom-up union and (triangles) the leaf-ordered triangle array: the LBVH's leaf order is the
+			// sorted order, so the thread that gathers a primitive's positions for its box writes its three records too
+			static const int refitPad = getenv("PT_REFIT_LDS_PAD") ? atoi(getenv("PT_REFIT_LDS_PAD")) : 0;  // tuning: occupancy limiter
+			k_refit<<<gridTris, kBlock, (size_t)refitPad, stream>>>(boxMode ? nullptr : triPos, triLo, triHi, vin, (int)n, topo, leafParent, bounds,
+			                                         boxes, arrive, padScale, tris);
 		}
 		if (err == hipSuccess && ploc)
 		{
@@ -1032,32 +1145,41 @@ hipError_t ptBuildBvh4(const PtBuildInput &in, PtBuildOutput &out, hipStream_t s
 			rootNode = n > 1 ? (int)(created - 1) : 0;
 			if (err == hipSuccess && n > 1 && created != n - 1) err = hipErrorAssert;
 		}
-		// collapse, level by level (host reads the queue length between levels; one-time build)
-		uint32_t init[4] = { 0u, 0u, 0u, 0u };
+		// collapse: every level's launch is enqueued at once, the level sizes stay on the device (k_collapse_level)
+		uint32_t init[64] = {};
+		init[8] = 1u;  // level 0 = the root
 		TRY(hipMemcpyAsync(counters, init, sizeof(init), hipMemcpyHostToDevice, stream));
 		CollapseTask root = { rootNode, 0u };
 		TRY(hipMemcpyAsync(taskA, &root, sizeof(root), hipMemcpyHostToDevice, stream));
-		uint32_t nIn = 1;
-		nodeCount = 1;
-		CollapseTask *tin = taskA, *tout = taskB;
-		while (err == hipSuccess && nIn > 0)
+		if (err == hipSuccess)
 		{
-			++depth;
-			k_collapse_level<<<divUp(nIn, kBlock), kBlock, 0, stream>>>(tin, nIn, tout, counters + 2, (int)n, children,
-			                                                          ploc ? nullptr : range, subCount, boxes, vin, boxMode,
-			                                                          leafPrim, nodes, nodeCount, counters + 1, leafMax,
-			                                                          in.nodeBase);
-			uint32_t h[4];
+			const Bvh2View view = { ploc ? nullptr : topo, ploc ? children : nullptr, ploc ? subCount : nullptr, (int)n };
+			const uint32_t grid = gridTris < 2048u ? gridTris : 2048u;
+			CollapseTask *tin = taskA, *tout = taskB;
+			for (int level = 0; level < kMaxLevels; ++level)
+			{
+				// a level cannot hold more wide nodes than 4^level: small grids for the top of the tree
+				const uint32_t cap = level < 10 ? divUp((size_t)1 << (2 * level), kBlock) : grid;
+				k_collapse_level<<<cap < grid ? cap : grid, kBlock, 0, stream>>>(tin, tout, counters + 8, level, view, boxes, vin, boxMode,
+				                                                                 leafPrim, nodes, counters + 1, leafMax, in.nodeBase);
+				CollapseTask *t = tin;
+				tin = tout;
+				tout = t;
+			}
+			uint32_t h[64];
 			err = hipMemcpyAsync(h, counters, sizeof(h), hipMemcpyDeviceToHost, stream);
 			TRY(hipStreamSynchronize(stream));
-			if (err != hipSuccess) break;
-			nIn = h[2];
-			nodeCount += nIn;
-			if (h[1] > n || nodeCount > n) { err = hipErrorAssert; break; }
-			TRY(hipMemsetAsync(counters + 2, 0, sizeof(uint32_t), stream));
-			CollapseTask *t = tin;
-			tin = tout;
-			tout = t;
+			if (err == hipSuccess)
+			{
+				nodeCount = 0;
+				for (int level = 0; level <= kMaxLevels; ++level)
+				{
+					if (h[8 + level] == 0) break;
+					++depth;  // (kMaxLevels + 1 = the tree did not fit: the caller rejects depths like that)
+					nodeCount += h[8 + level];
+				}
+				if (h[1] > n || nodeCount > n) err = hipErrorAssert;
+			}
 		}
 		if (err == hipSuccess && leafPrim) k_write_tris<<<gridTris, kBlock, 0, stream>>>(leafPrim, n, triPos, tris);
 		TRY(hipGetLastError());

@@ -53,7 +53,16 @@ constexpr int kStackLds = PT_STACK_LDS;   // traversal stack entries per lane he
 constexpr int kInFields = 11;   // ox oy oz ix iy iz Sx Sy Sz kpack(kz | signs | depth << 16) q   (+ dx dy dz: two-level)
 constexpr int kDoneFields = 6;  // V W det prim q kpack                                          (+ instance: two-level)
 constexpr int kSaveFields = 7;  // two-level: prepared world ray (ix iy iz Sx Sy Sz kpack) while a lane is inside an instance
-constexpr int kDoneRing = 128;
+#ifndef PT_DONE_RING
+#define PT_DONE_RING 128
+#endif
+constexpr int kDoneRing = PT_DONE_RING;  // >= 64 entries; below 127 a retire may have to shade a partial batch first
+// ring position p + i for p < kDoneRing, i <= kDoneRing (the ring length need not be a power of two)
+__device__ __forceinline__ uint32_t pt_ring_at(uint32_t p)
+{
+	if ((kDoneRing & (kDoneRing - 1)) == 0) return p & (uint32_t)(kDoneRing - 1);
+	return p >= (uint32_t)kDoneRing ? p - (uint32_t)kDoneRing : p;
+}
 constexpr uint32_t kRefillLanes = PT_REFILL_LANES;
 constexpr uint32_t kNoPath = 0xFFFFFFFFu;
 
@@ -97,6 +106,32 @@ __device__ __forceinline__ uint32_t popcWave(unsigned long long m)
 	asm("" : "+s"(n));
 	return n;
 }
+
+// Tuning builds only (-DPT_PATHS_TIMING): wall cycles of every section of the loop, summed per wave into a.trav[6 + section]
+// (s_memtime stamps; the stamps themselves cost ~10 % -- shares, not absolute times).
+#ifdef PT_PATHS_TIMING
+#define PT_T_SECTIONS 8
+#define PT_T_MARK(sec)                                               \
+	{                                                                \
+		const unsigned long long now_ = __builtin_amdgcn_s_memtime(); \
+		tcyc[tsec] += now_ - tlast;                                  \
+		tlast = now_;                                                \
+		tsec = (sec);                                                \
+	}
+#else
+#define PT_T_MARK(sec)
+#endif
+enum
+{
+	PT_T_LOOP = 0,   // loop head, votes, bookkeeping
+	PT_T_RETIRE = 1, // parking finished hits
+	PT_T_FLUSH = 2,  // shading
+	PT_T_RING = 3,   // staging survivors from the ring
+	PT_T_GEN = 4,    // claims + camera rays + staging
+	PT_T_TAKE = 5,   // idle lanes pick prepared rays up
+	PT_T_NODE = 6,
+	PT_T_LEAF = 7
+};
 
 // kInst: two-level scene (pt_set_instances).  A lane starts in the top-level tree (inst == PT_NO_INSTANCE), where
 // a leaf reference is an instance index: the lane saves its prepared world ray in LDS, transforms the ray with the
@@ -154,10 +189,14 @@ __global__ void __launch_bounds__(PT_WAVE) PT_PATHS_OCCUPANCY k_paths(PtPathsArg
 	uint32_t ringHead = 0, ringCount = 0;
 
 	uint32_t inCount = 0, inPos = 0;      // prepared rays in sIn
-	uint32_t doneHead = 0, doneTail = 0;  // LDS ring of finished rays
+	uint32_t doneHead = 0, doneCount = 0;  // LDS ring of finished rays: first entry (< kDoneRing) and entries parked
 	uint32_t raysFetched = 0;
 	uint32_t nodeFetches = 0, triTests = 0, nHits = 0, leafVisits = 0, nodeSteps = 0, leafSteps = 0;
 
+#ifdef PT_PATHS_TIMING
+	unsigned long long tcyc[PT_T_SECTIONS] = {}, tlast = __builtin_amdgcn_s_memtime();
+	int tsec = PT_T_LOOP;
+#endif
 	// per-lane ray state
 	float ox = 0, oy = 0, oz = 0, ix = 0, iy = 0, iz = 0, Sx = 0, Sy = 0, Sz = 0;
 	uint32_t kpack = 0, q = kNoPath;
@@ -188,7 +227,7 @@ __global__ void __launch_bounds__(PT_WAVE) PT_PATHS_OCCUPANCY k_paths(PtPathsArg
 		}
 		if ((uint32_t)lane < count)
 		{
-			uint32_t e = (doneHead + lane) & (kDoneRing - 1);
+			uint32_t e = pt_ring_at(doneHead + (uint32_t)lane);
 			uint32_t prim = sDone[3][e];
 			pq = sDone[4][e];
 			depth = sDone[5][e] >> 16;
@@ -228,7 +267,8 @@ __global__ void __launch_bounds__(PT_WAVE) PT_PATHS_OCCUPANCY k_paths(PtPathsArg
 				if (kStats) ++nHits;
 			}
 		}
-		doneHead += count;
+		doneHead = pt_ring_at(doneHead + count);
+		doneCount -= count;
 		unsigned long long am = __ballot(alive);
 		if (alive)
 		{
@@ -263,19 +303,30 @@ __global__ void __launch_bounds__(PT_WAVE) PT_PATHS_OCCUPANCY k_paths(PtPathsArg
 
 	for (;;)
 	{
+		PT_T_MARK(PT_T_LOOP)
 		// Retire + refill only when enough lanes wait for it (or nothing else is left to do): the section
 		// costs about half a node step, so it is not run for every single finished lane.
 		const uint32_t nIdle = popcWave(__ballot(cur == PT_TRAVERSAL_DONE));
 		if (nIdle >= kRefillLanes)
 		{
+			PT_T_MARK(PT_T_RETIRE)
 			// ------------------------------------------------------------------ C: retire finished lanes ----
 			bool fin = (q != kNoPath) && (cur == PT_TRAVERSAL_DONE);
 			unsigned long long fm = __ballot(fin);
 			if (fm)
 			{
+				if (kDoneRing < 2 * PT_WAVE - 1 && doneCount + popcWave(fm) > (uint32_t)kDoneRing)
+				{
+					// a ring shorter than 127 entries cannot always take the finished lanes: shade what is parked first
+					PT_T_MARK(PT_T_FLUSH)
+					__syncthreads();
+					flush(doneCount);
+					__syncthreads();
+					PT_T_MARK(PT_T_RETIRE)
+				}
 				if (fin)
 				{
-					uint32_t e = (doneTail + popc64(fm & lanesBelow)) & (kDoneRing - 1);
+					uint32_t e = pt_ring_at(pt_ring_at(doneHead + doneCount) + popc64(fm & lanesBelow));
 					sDone[0][e] = __float_as_uint(best.V);
 					sDone[1][e] = __float_as_uint(best.W);
 					sDone[2][e] = __float_as_uint(best.det);
@@ -285,14 +336,16 @@ __global__ void __launch_bounds__(PT_WAVE) PT_PATHS_OCCUPANCY k_paths(PtPathsArg
 					if (kInst) sDone[kDoneFields][e] = bestInst;
 					q = kNoPath;
 				}
-				doneTail += popcWave(fm);
-				if (doneTail - doneHead >= PT_WAVE)
+				doneCount += popcWave(fm);
+				if (doneCount >= PT_WAVE)
 				{
+					PT_T_MARK(PT_T_FLUSH)
 					__syncthreads();
 					flush(PT_WAVE);
 					__syncthreads();
 				}
 			}
+			PT_T_MARK(PT_T_TAKE)
 			// ------------------------------------------------------------------ A: refill idle lanes ----
 			unsigned long long idle = __ballot(cur == PT_TRAVERSAL_DONE);
 			while (idle)
@@ -303,6 +356,7 @@ __global__ void __launch_bounds__(PT_WAVE) PT_PATHS_OCCUPANCY k_paths(PtPathsArg
 					if (ringCount >= PT_WAVE || (genDone && ringCount > 0))
 					{
 						// continue paths of this wave: the next (up to) 64 survivors
+						PT_T_MARK(PT_T_RING)
 						n = ringCount < PT_WAVE ? ringCount : PT_WAVE;
 						__syncthreads();  // staging contents consumed; ring stores of earlier flushes complete
 						if ((uint32_t)lane < n)
@@ -316,6 +370,7 @@ __global__ void __launch_bounds__(PT_WAVE) PT_PATHS_OCCUPANCY k_paths(PtPathsArg
 					}
 					else if (!genDone)
 					{
+						PT_T_MARK(PT_T_GEN)
 						if (itemCur == itemEnd)
 						{
 							// Guided self-scheduling over the work items: a static first claim, then one atomic for
@@ -399,10 +454,10 @@ __global__ void __launch_bounds__(PT_WAVE) PT_PATHS_OCCUPANCY k_paths(PtPathsArg
 					else
 					{
 						// nothing to stage: in the drain, shade a partial batch early so its survivors keep lanes busy
-						if (doneTail != doneHead && popcWave(idle) >= 32u)
+						if (doneCount && popcWave(idle) >= 32u)
 						{
 							__syncthreads();
-							flush(doneTail - doneHead);
+							flush(doneCount);
 							__syncthreads();
 							if (ringCount) continue;
 						}
@@ -412,6 +467,7 @@ __global__ void __launch_bounds__(PT_WAVE) PT_PATHS_OCCUPANCY k_paths(PtPathsArg
 					inCount = n;
 					inPos = 0;
 					raysFetched += n;
+					PT_T_MARK(PT_T_TAKE)
 				}
 				uint32_t avail = inCount - inPos, want = popcWave(idle);
 				uint32_t n = want < avail ? want : avail;
@@ -458,10 +514,10 @@ __global__ void __launch_bounds__(PT_WAVE) PT_PATHS_OCCUPANCY k_paths(PtPathsArg
 			{
 				// no lane holds a path and nothing could be staged: shade what is parked (its survivors come
 				// back through the ring), or leave when that is empty too
-				if (doneTail != doneHead)
+				if (doneCount)
 				{
 					__syncthreads();
-					flush(doneTail - doneHead);
+					flush(doneCount);
 					__syncthreads();
 					continue;
 				}
@@ -472,6 +528,7 @@ __global__ void __launch_bounds__(PT_WAVE) PT_PATHS_OCCUPANCY k_paths(PtPathsArg
 
 		// ------------------------------------------------------------------ B: traverse ----
 		// One step for the LARGER of the two groups (majority-phase stepping, see pt_bounce.hip).
+		PT_T_MARK(PT_T_LOOP)
 		const unsigned long long nodeLanes = __ballot(!(cur & PT_LEAF_FLAG));
 		const unsigned long long leafLanes = __ballot((cur & PT_LEAF_FLAG) && cur != PT_TRAVERSAL_DONE);
 		const bool doNode = popcWave(nodeLanes) >= popcWave(leafLanes);
@@ -481,6 +538,7 @@ __global__ void __launch_bounds__(PT_WAVE) PT_PATHS_OCCUPANCY k_paths(PtPathsArg
 			if (doNode) ++nodeSteps;  // wave-uniform
 			else ++leafSteps;
 		}
+		PT_T_MARK(doNode ? PT_T_NODE : PT_T_LEAF)
 		if (doNode && !(cur & PT_LEAF_FLAG))
 		{
 			if (kStats) ++nodeFetches;
@@ -553,6 +611,11 @@ __global__ void __launch_bounds__(PT_WAVE) PT_PATHS_OCCUPANCY k_paths(PtPathsArg
 		}
 	}
 
+#ifdef PT_PATHS_TIMING
+	PT_T_MARK(PT_T_LOOP)
+	if (lane == 0 && a.trav)
+		for (int i = 0; i < PT_T_SECTIONS; ++i) atomicAdd(&a.trav[6 + i], tcyc[i]);
+#endif
 	if (lane == 0 && raysFetched) PT_COLD(waveRays)[blockIdx.x] += raysFetched;  // one wave per slot: no atomic needed
 	if (kStats)
 	{

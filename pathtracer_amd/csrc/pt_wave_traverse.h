@@ -83,7 +83,9 @@ enum
 	PT_NODES_PLANES = 2
 };
 #define PT_LDS_NODES_PACKED 16u
+#ifndef PT_LDS_NODES_PLANES
 #define PT_LDS_NODES_PLANES 8u
+#endif
 // decoded record, in 16-byte units: [0] origin.xyz, scaleX  [1] child references  [2] scaleY, scaleZ, -, -
 // [3..5] low planes x, y, z (one float per child)  [6..8] high planes x, y, z
 #define PT_PLANE_REC 9u
