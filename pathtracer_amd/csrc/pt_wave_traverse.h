@@ -292,6 +292,9 @@ __device__ __forceinline__ void pt_leaf_step(const PtSceneDev &sc, const PtLaneR
 	auto inside = [](float &U, float &V, float &W, float &det, float Ax, float Ay, float Bx, float By, float Cx, float Cy) {
 		if (U == 0.0f || V == 0.0f || W == 0.0f)
 		{
+			// rare (a ray through an edge or a vertex).  The empty asm pins the conversions inside the branch: left alone the
+			// compiler hoists part of the double-precision work (v_cvt_f64_f32, v_mul_f64: half rate) into every leaf step
+			asm volatile("" : "+v"(Ax), "+v"(Ay), "+v"(Bx), "+v"(By), "+v"(Cx), "+v"(Cy));
 			U = (float)((double)Cx * (double)By - (double)Cy * (double)Bx);
 			V = (float)((double)Ax * (double)Cy - (double)Ay * (double)Cx);
 			W = (float)((double)Bx * (double)Ay - (double)By * (double)Ax);
