@@ -148,6 +148,8 @@ int pt_set_texture(pt_ctx *ctx, const uint8_t *rgba8, uint32_t width, uint32_t h
 #define PT_ACCEL_BVH4_PLOC 2    /* same sort, BVH2 by parallel locally-ordered clustering (radius 16), same BVH4 */
 #define PT_ACCEL_LEAF_SIZE(n) ((n) << 8) /* OR into flags: at most n (1..8) triangles per leaf; 0 = default */
 #define PT_ACCEL_NO_COMPACTION 0x1000    /* buildBlas(..., allowCompaction = false), VulkanRaytracing.cpp:150,170 */
+#define PT_ACCEL_NO_ENTRY_NODE 0x2000    /* no flattened tree top: every ray of the persistent pipeline starts at the root (same
+                                            images; node-visit statistics then equal the other pipelines') */
 
 /* VulkanRaytracing::buildBlas + buildTlas (VulkanRaytracing.cpp:147-262,448-527): what the
  * Vulkan driver did inside vkCmdBuildAccelerationStructuresKHR.  One BLAS, one identity

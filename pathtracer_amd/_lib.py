@@ -17,6 +17,7 @@ PT_ACCEL_BVH4 = 0
 PT_ACCEL_BRUTE_FORCE = 1
 PT_ACCEL_BVH4_PLOC = 2
 PT_ACCEL_NO_COMPACTION = 0x1000
+PT_ACCEL_NO_ENTRY_NODE = 0x2000
 PT_ACCEL_LEAF_SIZE_1 = 1 << 8  # PT_ACCEL_LEAF_SIZE(1)
 
 

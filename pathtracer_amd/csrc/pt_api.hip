@@ -72,6 +72,7 @@ struct pt_ctx
 	uint32_t texW = 0, texH = 0;
 	PtBuildOutput accel;
 	PtQuadOutput quadAccel;  // quad leaves + the node array that refers to them (persistent pipeline only)
+	uint4 *dEntry = nullptr;  // entry node of the persistent pipeline (flattened tree top, pt_wave_traverse.h) or nullptr
 	double buildMs = 0.0;
 	uint64_t accelBytes = 0, accelBytesUncompacted = 0;  // acceleration-structure memory after / before compaction
 	// two-level scenes (pt_set_instances): 24 floats per instance (object-to-world 3x4, world-to-object 3x4)
@@ -165,6 +166,8 @@ void freeAccel(pt_ctx *c)
 	hipFree(c->quadAccel.nodes);
 	hipFree(c->quadAccel.quads);
 	c->quadAccel = PtQuadOutput();
+	hipFree(c->dEntry);
+	c->dEntry = nullptr;
 	c->haveAccel = false;
 }
 
@@ -607,7 +610,7 @@ extern "C" int pt_build_accel(pt_ctx *c, int flags) try
 	if (!c->haveScene) return fail(c, PT_EINVAL, "pt_build_accel: no scene uploaded");
 	const int mode = flags & 0xFF, leafMax = (flags >> 8) & 0xF;
 	const bool compact = !(flags & PT_ACCEL_NO_COMPACTION);
-	if ((mode != PT_ACCEL_BVH4 && mode != PT_ACCEL_BRUTE_FORCE && mode != PT_ACCEL_BVH4_PLOC) || (flags & ~0x1FFF) || leafMax > 8)
+	if ((mode != PT_ACCEL_BVH4 && mode != PT_ACCEL_BRUTE_FORCE && mode != PT_ACCEL_BVH4_PLOC) || (flags & ~0x3FFF) || leafMax > 8)
 		return fail(c, PT_EINVAL, "pt_build_accel: bad flags 0x%x", flags);
 	PT_HIP(c, hipSetDevice(c->device));
 	PT_HIP(c, hipStreamSynchronize(c->stream));
@@ -665,6 +668,17 @@ extern "C" int pt_build_accel(pt_ctx *c, int flags) try
 		{
 			freeAccel(c);
 			return fail(c, PT_EHIP, "pt_build_accel: quad leaves failed: %s", hipGetErrorString(qe));
+		}
+	}
+	if (!c->nInst && !c->brute && c->accel.nNodes && !(flags & PT_ACCEL_NO_ENTRY_NODE) && !getenv("PT_NO_ENTRY"))
+	{
+		// the tree top as one wide node that k_paths tests while it stages a ray (of the node array k_paths traverses)
+		hipError_t ee = ptBuildEntryNode(c->quadAccel.nQuads ? c->quadAccel.nodes : c->accel.nodes, c->accel.nNodes, 0u, &c->dEntry,
+		                                 c->stream);
+		if (ee != hipSuccess)
+		{
+			freeAccel(c);
+			return fail(c, PT_EHIP, "pt_build_accel: entry node failed: %s", hipGetErrorString(ee));
 		}
 	}
 	if (c->nInst && !c->brute && c->accel.nNodes)
@@ -1013,6 +1027,7 @@ int renderPersistent(pt_ctx *c, int n, bool noAlloc = false)
 		pa.instances = c->dInstances;
 		pa.nInst = c->tlasDepth ? c->nInst : 0;
 		pa.tlasRoot = c->tlasRoot;
+		pa.entry = pa.nInst ? nullptr : c->dEntry;
 		ptLaunchPaths(pa, waves, statsKernel, s);
 		if (e1) hipEventRecord(e1, s);
 		ptLaunchAccumulateItems(rad, tile, c->W, (uint32_t)c->spp, c->image, frame0, batch, c->accumMode, s);

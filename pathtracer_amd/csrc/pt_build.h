@@ -46,3 +46,8 @@ struct PtQuadOutput
 };
 hipError_t ptBuildQuadLeaves(const PtNode4 *nodes, uint32_t nNodes, const PtTri48 *tris, uint32_t nTris, float minShare,
                              PtQuadOutput &out, hipStream_t stream);
+
+// Entry node for k_paths (pt_wave_traverse.h): the top of the tree under `root` flattened into one node of up to
+// PT_ENTRY_WIDTH children, as a decoded record of PT_ENTRY_REC 16-byte units in device memory (*rec; nullptr when the tree
+// is empty).  Synchronises the stream.  The caller owns the allocation.
+hipError_t ptBuildEntryNode(const PtNode4 *nodes, uint32_t nNodes, uint32_t root, uint4 **rec, hipStream_t stream);

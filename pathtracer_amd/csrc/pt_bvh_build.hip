@@ -1324,3 +1324,146 @@ hipError_t ptBuildQuadLeaves(const PtNode4 *nodes, uint32_t nNodes, const PtTri4
 	hipFree(flags);
 	return e;
 }
+
+// -------------------------------------------------------------------------- entry node ----
+namespace
+{
+// One thread: the top of the tree is a handful of nodes.  Starting from the root's children, the inner child with the
+// largest box is replaced by its own children while the list still fits PT_ENTRY_WIDTH; the boxes (dequantised with the
+// fmaf the builder verified them with) are then re-quantised in the frame of their union exactly as k_collapse_level
+// quantises a node -- conservative by the same check -- and stored decoded (pt_wave_traverse.h).
+__global__ void k_entry_node(const PtNode4 *nodes, uint32_t nNodes, uint32_t root, float4 *rec)
+{
+	if (threadIdx.x != 0 || blockIdx.x != 0) return;
+	constexpr int W = PT_ENTRY_WIDTH, G = W / 4;
+	uint32_t ref[W];
+	float lo[W][3], hi[W][3];
+	int n = 0;
+	auto childrenOf = [&](uint32_t node, int at, int &count) {
+		// children of `node`: the first replaces entry `at`, the others are appended; returns how many there were
+		const PtNode4 nd = nodes[node];
+		const float sc[3] = { nd.scaleX, nd.scaleY, nd.scaleZ };
+		count = 0;
+		for (int c = 0; c < 4; ++c)
+		{
+			if (nd.child[c] == PT_EMPTY_CHILD) continue;
+			const int dst = count == 0 ? at : n++;
+			ref[dst] = nd.child[c];
+			for (int a = 0; a < 3; ++a)
+			{
+				lo[dst][a] = __builtin_fmaf((float)((nd.qlo[a] >> (8 * c)) & 0xFFu), sc[a], nd.origin[a]);
+				hi[dst][a] = __builtin_fmaf((float)((nd.qhi[a] >> (8 * c)) & 0xFFu), sc[a], nd.origin[a]);
+			}
+			++count;
+		}
+	};
+	auto liveChildren = [&](uint32_t node) {
+		int k = 0;
+		for (int c = 0; c < 4; ++c) k += nodes[node].child[c] != PT_EMPTY_CHILD ? 1 : 0;
+		return k;
+	};
+	{
+		int k;
+		n = 1;  // entry 0 is a placeholder the root's first child replaces
+		childrenOf(root, 0, k);
+		if (k == 0) n = 0;
+	}
+	for (;;)
+	{
+		int best = -1;
+		float bestArea = -1.0f;
+		for (int i = 0; i < n; ++i)
+		{
+			if (ref[i] & PT_LEAF_FLAG) continue;
+			const int k = liveChildren(ref[i]);
+			if (k == 0 || n - 1 + k > W) continue;
+			const float dx = hi[i][0] - lo[i][0], dy = hi[i][1] - lo[i][1], dz = hi[i][2] - lo[i][2];
+			const float area = (dx * dy + dy * dz) + dz * dx;
+			if (area > bestArea)
+			{
+				bestArea = area;
+				best = i;
+			}
+		}
+		if (best < 0) break;
+		int k;
+		childrenOf(ref[best], best, k);
+	}
+	float org[3] = { INFINITY, INFINITY, INFINITY }, top[3] = { -INFINITY, -INFINITY, -INFINITY }, scale[3];
+	for (int i = 0; i < n; ++i)
+		for (int a = 0; a < 3; ++a)
+		{
+			org[a] = fminf(org[a], lo[i][a]);
+			top[a] = fmaxf(top[a], hi[i][a]);
+		}
+	for (int a = 0; a < 3; ++a)
+	{
+		if (n == 0) org[a] = top[a] = 0.0f;
+		float ext = top[a] - org[a];
+		int e = 1;
+		if (ext > 0.0f)
+		{
+			int ex2;
+			float m = frexpf(ext / 255.0f, &ex2);
+			e = (m == 0.5f ? ex2 - 1 : ex2) + 127;
+		}
+		if (e < 1) e = 1;
+		if (e > 254) e = 254;
+		float sc = __uint_as_float((uint32_t)e << 23);
+		while (e < 254 && !(__builtin_fmaf(255.0f, sc, org[a]) >= top[a]))
+		{
+			++e;
+			sc = __uint_as_float((uint32_t)e << 23);
+		}
+		scale[a] = sc;
+	}
+	float *out = reinterpret_cast<float *>(rec);
+	uint32_t *outU = reinterpret_cast<uint32_t *>(rec);
+	out[0] = org[0];
+	out[1] = org[1];
+	out[2] = org[2];
+	out[3] = scale[0];
+	out[4] = scale[1];
+	out[5] = scale[2];
+	outU[6] = (uint32_t)n;
+	outU[7] = 0u;
+	for (int i = 0; i < W; ++i)
+	{
+		outU[8 + i] = i < n ? ref[i] : PT_EMPTY_CHILD;
+		for (int a = 0; a < 3; ++a)
+		{
+			float ql = INFINITY, qh = -INFINITY;
+			if (i < n)
+			{
+				ql = floorf((lo[i][a] - org[a]) / scale[a]);
+				ql = fminf(fmaxf(ql, 0.0f), 255.0f);
+				while (ql > 0.0f && __builtin_fmaf(ql, scale[a], org[a]) > lo[i][a]) ql -= 1.0f;
+				qh = ceilf((hi[i][a] - org[a]) / scale[a]);
+				qh = fminf(fmaxf(qh, 0.0f), 255.0f);
+				while (qh < 255.0f && __builtin_fmaf(qh, scale[a], org[a]) < hi[i][a]) qh += 1.0f;
+			}
+			out[4 * (2 + G) + (0 + a) * W + i] = ql;
+			out[4 * (2 + G) + (3 + a) * W + i] = qh;
+		}
+	}
+}
+}  // namespace
+
+hipError_t ptBuildEntryNode(const PtNode4 *nodes, uint32_t nNodes, uint32_t root, uint4 **rec, hipStream_t stream)
+{
+	*rec = nullptr;
+	if (!nNodes || root >= nNodes) return hipSuccess;
+	uint4 *d = nullptr;
+	hipError_t e = hipMalloc(&d, sizeof(uint4) * PT_ENTRY_REC);
+	if (e != hipSuccess) return e;
+	k_entry_node<<<1, 64, 0, stream>>>(nodes, nNodes, root, reinterpret_cast<float4 *>(d));
+	e = hipGetLastError();
+	if (e == hipSuccess) e = hipStreamSynchronize(stream);
+	if (e != hipSuccess)
+	{
+		hipFree(d);
+		return e;
+	}
+	*rec = d;
+	return hipSuccess;
+}

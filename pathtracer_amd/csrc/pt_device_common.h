@@ -376,6 +376,12 @@ static_assert(sizeof(PtNode4) == 64, "PtNode4 must be 64 bytes");
 #define PT_LEAF_MAX 8      // the leaf reference has 3 bits for (count - 1)
 #define PT_LEAF_DEFAULT 2
 
+// Entry node (pt_wave_traverse.h): children of the flattened tree top, and the size of its decoded record in 16-byte units.
+#ifndef PT_ENTRY_WIDTH
+#define PT_ENTRY_WIDTH 16
+#endif
+#define PT_ENTRY_REC (2u + 7u * PT_ENTRY_WIDTH / 4u)
+
 // 48-byte leaf triangle: three 16-byte loads.  (v0.xyz, v1.x) (v1.yz, v2.xy) (v2.z, prim, -, -)
 struct __attribute__((aligned(16))) PtTri48
 {

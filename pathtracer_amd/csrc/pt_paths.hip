@@ -49,15 +49,23 @@ namespace
 #else
 #define PT_PATHS_OCCUPANCY
 #endif
-constexpr int kStackLds = PT_STACK_LDS;   // traversal stack entries per lane held in LDS; deeper ones spill to global
-constexpr int kInFields = 11;   // ox oy oz ix iy iz Sx Sy Sz kpack(kz | signs | depth << 16) q   (+ dx dy dz: two-level)
+constexpr int kStackLdsFull = PT_STACK_LDS;   // traversal stack entries per lane held in LDS; deeper ones spill to global
+// the variants that hold a node copy AND the entry node in LDS keep 16 waves per CU (10 240 B each) with a shorter stack
+// and done ring: their trees have at most 16 nodes (depth <= 3 below the entry node: 9 pending entries + the sentinel)
+constexpr int kStackLdsTiny = 10;
+constexpr int kInFields = 11;   // ox oy oz ix iy iz Sx Sy Sz kpack(kz | signs | depth << 16) q   (+ entry children hit) (+ dx dy dz: two-level)
 constexpr int kDoneFields = 6;  // V W det prim q kpack                                          (+ instance: two-level)
 constexpr int kSaveFields = 7;  // two-level: prepared world ray (ix iy iz Sx Sy Sz kpack) while a lane is inside an instance
 #ifndef PT_DONE_RING
 #define PT_DONE_RING 128
 #endif
-constexpr int kDoneRing = PT_DONE_RING;  // >= 64 entries; below 127 a retire may have to shade a partial batch first
+constexpr int kDoneRingFull = PT_DONE_RING;  // >= 64 entries; below 127 a retire may have to shade a partial batch first
+#ifndef PT_DONE_RING_TINY
+#define PT_DONE_RING_TINY 112
+#endif
+constexpr int kDoneRingTiny = PT_DONE_RING_TINY;             // (only when more than 32 lanes retire at once onto more than 32 parked hits)
 // ring position p + i for p < kDoneRing, i <= kDoneRing (the ring length need not be a power of two)
+template <int kDoneRing>
 __device__ __forceinline__ uint32_t pt_ring_at(uint32_t p)
 {
 	if ((kDoneRing & (kDoneRing - 1)) == 0) return p & (uint32_t)(kDoneRing - 1);
@@ -137,12 +145,26 @@ enum
 // a leaf reference is an instance index: the lane saves its prepared world ray in LDS, transforms the ray with the
 // instance's world-to-object matrix (direction NOT renormalised: t means the same in both spaces), pushes
 // PT_INSTANCE_END and descends into the bottom-level tree; popping the marker restores the world ray.
-template <bool kStats, bool kInst, int kNodeMode>
+// kEntry: the scene has an entry node (a.entry; pt_wave_traverse.h): the staging phase tests every fresh ray against it
+// and hands the lane that takes the ray the set of children it hits; the lane visits them one after the other.
+template <bool kStats, bool kInst, int kNodeMode, bool kEntry>
 __global__ void __launch_bounds__(PT_WAVE) PT_PATHS_OCCUPANCY k_paths(PtPathsArgs a)
 {
+	static_assert(!(kEntry && kInst), "the entry node is built for single-level scenes");
+	constexpr bool kTiny = kEntry && kNodeMode != PT_NODES_GLOBAL;
+	constexpr int kStackLds = kTiny ? kStackLdsTiny : kStackLdsFull;
+	constexpr int kDoneRing = kTiny ? kDoneRingTiny : kDoneRingFull;
+	constexpr int kInEntry = kInFields;  // entry children the ray hits (kEntry) / first row of the world direction (kInst)
+	constexpr int kInDir = kInFields;
 	__shared__ uint32_t sStack[kStackLds][PT_WAVE];
-	__shared__ uint32_t sIn[kInFields + (kInst ? 3 : 0)][PT_WAVE];
+	__shared__ uint32_t sIn[kInFields + (kInst ? 3 : 0) + (kEntry ? 1 : 0)][PT_WAVE];
 	__shared__ uint32_t sDone[kDoneFields + (kInst ? 1 : 0)][kDoneRing];
+	__shared__ uint4 sEntry[kEntry ? PT_ENTRY_REC : 1];
+	if (kEntry)
+	{
+		if (threadIdx.x < PT_ENTRY_REC) sEntry[threadIdx.x] = a.entry[threadIdx.x];
+		__syncthreads();
+	}
 	__shared__ uint32_t sSave[kInst ? kSaveFields : 1][PT_WAVE];
 	// tiny scenes (e.g. the Cornell box's 7 wide nodes): a wave-private copy of the node array, decoded (PT_NODES_PLANES) or
 	// as it is (PT_NODES_PACKED); see pt_wave_traverse.h
@@ -202,6 +224,7 @@ __global__ void __launch_bounds__(PT_WAVE) PT_PATHS_OCCUPANCY k_paths(PtPathsArg
 	uint32_t kpack = 0, q = kNoPath;
 	float wox = 0, woy = 0, woz = 0, wdx = 0, wdy = 0, wdz = 0;  // world ray (two-level scenes)
 	uint32_t inst = PT_NO_INSTANCE, bestInst = 0;
+	uint32_t pend = 0;  // entry-node children the lane's ray hits and has not visited yet (kEntry)
 	PtBest best = { tmax, PT_NO_HIT, 0.0f, 0.0f, 1.0f };
 	uint32_t cur = PT_TRAVERSAL_DONE;
 	int sp = 0;
@@ -227,7 +250,7 @@ __global__ void __launch_bounds__(PT_WAVE) PT_PATHS_OCCUPANCY k_paths(PtPathsArg
 		}
 		if ((uint32_t)lane < count)
 		{
-			uint32_t e = pt_ring_at(doneHead + (uint32_t)lane);
+			uint32_t e = pt_ring_at<kDoneRing>(doneHead + (uint32_t)lane);
 			uint32_t prim = sDone[3][e];
 			pq = sDone[4][e];
 			depth = sDone[5][e] >> 16;
@@ -267,7 +290,7 @@ __global__ void __launch_bounds__(PT_WAVE) PT_PATHS_OCCUPANCY k_paths(PtPathsArg
 				if (kStats) ++nHits;
 			}
 		}
-		doneHead = pt_ring_at(doneHead + count);
+		doneHead = pt_ring_at<kDoneRing>(doneHead + count);
 		doneCount -= count;
 		unsigned long long am = __ballot(alive);
 		if (alive)
@@ -293,17 +316,28 @@ __global__ void __launch_bounds__(PT_WAVE) PT_PATHS_OCCUPANCY k_paths(PtPathsArg
 		sIn[8][lane] = __float_as_uint(pr.Sz);
 		sIn[9][lane] = pr.kpack | (depth << 16);
 		sIn[10][lane] = pq;
+		if (kEntry)
+		{
+			sIn[kInEntry][lane] = pt_entry_test(sEntry, pr, tmin, tmax);
+			if (kStats) ++nodeFetches;  // one (wide) node visit
+		}
 		if (kInst)
 		{
-			sIn[kInFields + 0][lane] = __float_as_uint(d.x);
-			sIn[kInFields + 1][lane] = __float_as_uint(d.y);
-			sIn[kInFields + 2][lane] = __float_as_uint(d.z);
+			sIn[kInDir + 0][lane] = __float_as_uint(d.x);
+			sIn[kInDir + 1][lane] = __float_as_uint(d.y);
+			sIn[kInDir + 2][lane] = __float_as_uint(d.z);
 		}
 	};
 
 	for (;;)
 	{
 		PT_T_MARK(PT_T_LOOP)
+		if (kEntry && cur == PT_TRAVERSAL_DONE && pend != 0u)
+		{
+			// the subtree of one entry child is finished (the sentinel was popped): on to the next child the ray hits
+			cur = pt_entry_next(sEntry, pend);
+			sp = 1;
+		}
 		// Retire + refill only when enough lanes wait for it (or nothing else is left to do): the section
 		// costs about half a node step, so it is not run for every single finished lane.
 		const uint32_t nIdle = popcWave(__ballot(cur == PT_TRAVERSAL_DONE));
@@ -326,7 +360,7 @@ __global__ void __launch_bounds__(PT_WAVE) PT_PATHS_OCCUPANCY k_paths(PtPathsArg
 				}
 				if (fin)
 				{
-					uint32_t e = pt_ring_at(pt_ring_at(doneHead + doneCount) + popc64(fm & lanesBelow));
+					uint32_t e = pt_ring_at<kDoneRing>(pt_ring_at<kDoneRing>(doneHead + doneCount) + popc64(fm & lanesBelow));
 					sDone[0][e] = __float_as_uint(best.V);
 					sDone[1][e] = __float_as_uint(best.W);
 					sDone[2][e] = __float_as_uint(best.det);
@@ -492,9 +526,9 @@ __global__ void __launch_bounds__(PT_WAVE) PT_PATHS_OCCUPANCY k_paths(PtPathsArg
 						wox = ox;
 						woy = oy;
 						woz = oz;
-						wdx = __uint_as_float(sIn[kInFields + 0][s]);
-						wdy = __uint_as_float(sIn[kInFields + 1][s]);
-						wdz = __uint_as_float(sIn[kInFields + 2][s]);
+						wdx = __uint_as_float(sIn[kInDir + 0][s]);
+						wdy = __uint_as_float(sIn[kInDir + 1][s]);
+						wdz = __uint_as_float(sIn[kInDir + 2][s]);
 						inst = PT_NO_INSTANCE;
 						bestInst = 0;
 					}
@@ -506,6 +540,13 @@ __global__ void __launch_bounds__(PT_WAVE) PT_PATHS_OCCUPANCY k_paths(PtPathsArg
 					sStack[0][lane] = PT_TRAVERSAL_DONE;  // sentinel: popping an empty stack ends the traversal
 					sp = 1;
 					cur = sc.nNodes ? (kInst ? a.tlasRoot : 0u) : PT_TRAVERSAL_DONE;
+					if (kEntry)
+					{
+						// the children of the entry node the ray hits (tested while it was staged): the first one now, the
+						// others when the traversal below it has emptied the stack (loop head); none: the ray misses the scene
+						pend = sIn[kInEntry][s];
+						cur = pend ? pt_entry_next(sEntry, pend) : PT_TRAVERSAL_DONE;
+					}
 				}
 				inPos += n;
 				idle &= ~__ballot(take);
@@ -715,26 +756,21 @@ void ptLaunchPaths(const PtPathsArgs &args, uint32_t waves, bool stats, hipStrea
 	// A/B knobs: PT_LDS_NODES_OFF = nodes from memory whatever the size, PT_LDS_PLANES_OFF = packed LDS copy only
 	static const bool ldsOff = getenv("PT_LDS_NODES_OFF") != nullptr, planesOff = getenv("PT_LDS_PLANES_OFF") != nullptr;
 	const uint32_t nNodes = args.sc.nNodes;
-	if (args.nInst)
-	{
-		if (stats) k_paths<true, true, PT_NODES_GLOBAL><<<waves, PT_WAVE, 0, s>>>(args);
-		else k_paths<false, true, PT_NODES_GLOBAL><<<waves, PT_WAVE, 0, s>>>(args);
+#define PT_LAUNCH(inst, mode)                                                                        \
+	{                                                                                                \
+		if (args.entry && !(inst))                                                                   \
+		{                                                                                            \
+			if (stats) k_paths<true, false, mode, true><<<waves, PT_WAVE, 0, s>>>(args);             \
+			else k_paths<false, false, mode, true><<<waves, PT_WAVE, 0, s>>>(args);                  \
+		}                                                                                            \
+		else if (stats) k_paths<true, inst, mode, false><<<waves, PT_WAVE, 0, s>>>(args);            \
+		else k_paths<false, inst, mode, false><<<waves, PT_WAVE, 0, s>>>(args);                      \
 	}
-	else if (nNodes && nNodes <= PT_LDS_NODES_PLANES && !ldsOff && !planesOff)
-	{
-		if (stats) k_paths<true, false, PT_NODES_PLANES><<<waves, PT_WAVE, 0, s>>>(args);
-		else k_paths<false, false, PT_NODES_PLANES><<<waves, PT_WAVE, 0, s>>>(args);
-	}
-	else if (nNodes && nNodes <= PT_LDS_NODES_PACKED && !ldsOff)
-	{
-		if (stats) k_paths<true, false, PT_NODES_PACKED><<<waves, PT_WAVE, 0, s>>>(args);
-		else k_paths<false, false, PT_NODES_PACKED><<<waves, PT_WAVE, 0, s>>>(args);
-	}
-	else
-	{
-		if (stats) k_paths<true, false, PT_NODES_GLOBAL><<<waves, PT_WAVE, 0, s>>>(args);
-		else k_paths<false, false, PT_NODES_GLOBAL><<<waves, PT_WAVE, 0, s>>>(args);
-	}
+	if (args.nInst) PT_LAUNCH(true, PT_NODES_GLOBAL)
+	else if (nNodes && nNodes <= PT_LDS_NODES_PLANES && !ldsOff && !planesOff) PT_LAUNCH(false, PT_NODES_PLANES)
+	else if (nNodes && nNodes <= PT_LDS_NODES_PACKED && !ldsOff) PT_LAUNCH(false, PT_NODES_PACKED)
+	else PT_LAUNCH(false, PT_NODES_GLOBAL)
+#undef PT_LAUNCH
 }
 
 void ptLaunchAccumulateItems(const float4 *rad, PtTile tile, uint32_t W, uint32_t spp, float4 *image, uint32_t lframe0,

@@ -4,7 +4,7 @@
 
 #define PT_MAX_DEPTH 64     // upper bound for max_depth (reference: 20)
 #define PT_SPILL_STACK 72   // traversal stack entries per lane beyond the LDS-resident ones
-#define PT_STACK_CAPACITY (12 + PT_SPILL_STACK)  // smallest traversal stack of any kernel: LDS entries + spill
+#define PT_STACK_CAPACITY (10 + PT_SPILL_STACK)  // smallest traversal stack of any kernel: LDS entries + spill
 #define PT_CHUNK 1024u      // queue records per chunk (work-claim and compaction granularity)
 
 // Sub-rectangle of the image a dispatch covers (pt_set_tile; default = the whole image).  Tile pixel t maps to
@@ -90,6 +90,7 @@ struct PtPathsArgs
 	// sc.nodes holds the bottom-level tree at index 0 and the top-level tree at tlasRoot; nInst == 0: single level
 	const float *instances;
 	uint32_t nInst, tlasRoot;
+	const uint4 *entry;  // entry node (PT_ENTRY_REC 16-byte units, pt_wave_traverse.h) or nullptr: every ray starts at the root
 };
 void ptLaunchPaths(const PtPathsArgs &args, uint32_t waves, bool stats, hipStream_t s);
 void ptLaunchStoreCamera(const PtCamera &cam, PtCamera *dst, hipStream_t s);

@@ -251,6 +251,70 @@ __device__ __forceinline__ void pt_node_step(const PtSceneDev &sc, const PtLaneR
 	}
 }
 
+// ---------------------------------------------------------------------------------- entry node ----
+// The top of the tree flattened into ONE wide node (pt_build.h, ptBuildEntryNode) that k_paths tests in its STAGING phase,
+// where all 64 lanes hold a fresh ray -- the first node visits of every ray at full lane utilisation instead of inside the
+// traversal loop at ~0.68, and as one wide step instead of two or three 4-wide ones (Cornell: root + the two room-sized
+// nodes every ray is inside = 3.04 visits of 105 instructions -> one 8-wide test).  Record, in 16-byte units (W = width):
+//   [0] origin.xyz, scaleX   [1] scaleY, scaleZ, children, -   [2 .. 2+W/4) child references
+//   then six plane arrays of W floats: lo x, lo y, lo z, hi x, hi y, hi z -- the quantised planes as floats, as in the
+//   decoded node records above (same fma, near/far picked by address, an empty slot is lo = +inf / hi = -inf).
+// The children keep their ordinary references (leaves, quad leaves, inner nodes of the ordinary array), so what follows the
+// entry test is the ordinary traversal; the flattened nodes stay in the array for rays that do not use the entry node.
+// (PT_ENTRY_WIDTH, PT_ENTRY_REC: pt_device_common.h)
+// Tests `ray` against the entry node (best hit so far: none, so the interval is [tmin, tmax]) and returns the set of
+// children it hits as a bit mask: child c is bit PT_ENTRY_WIDTH-1-c.  The lane that traverses the ray keeps the mask in a
+// register and visits the children one after the other, lowest bit first (pt_entry_next), each with the ordinary stack
+// discipline -- nothing is stored per child, and there is no limit on how many a ray may hit.
+__device__ __forceinline__ uint32_t pt_entry_test(const uint4 *e, const PtLaneRay &ray, float tmin, float tmax)
+{
+	constexpr int W = PT_ENTRY_WIDTH, G = W / 4;
+	const float4 *rec = reinterpret_cast<const float4 *>(e);
+	const float4 h0 = rec[0], h1 = rec[1];
+	const bool negx = ray.kpack & 64u, negy = ray.kpack & 128u, negz = ray.kpack & 256u;
+	const float ax = h0.w * ray.ix, ay = h1.x * ray.iy, az = h1.y * ray.iz;
+	const float bx = (h0.x - ray.ox) * ray.ix, by = (h0.y - ray.oy) * ray.iy, bz = (h0.z - ray.oz) * ray.iz;
+	const float4 *planes = rec + 2 + G;
+	const int nx = negx ? 3 * G : 0, ny = negy ? 3 * G : 0, nz = negz ? 3 * G : 0;
+	uint32_t mask = 0;
+#pragma unroll
+	for (int g = 0; g < G; ++g)
+	{
+		// one group of four children at a time: left alone the compiler issues the loads of all groups first (28 x 16 bytes
+		// per lane for 16 children) and the kernel loses a wave of occupancy to the registers that hold them
+		asm volatile("" ::: "memory");
+		const float4 qnx = planes[0 * G + nx + g], qfx = planes[3 * G - nx + g];
+		const float4 qny = planes[1 * G + ny + g], qfy = planes[4 * G - ny + g];
+		const float4 qnz = planes[2 * G + nz + g], qfz = planes[5 * G - nz + g];
+		const float vnx[4] = { qnx.x, qnx.y, qnx.z, qnx.w }, vfx[4] = { qfx.x, qfx.y, qfx.z, qfx.w };
+		const float vny[4] = { qny.x, qny.y, qny.z, qny.w }, vfy[4] = { qfy.x, qfy.y, qfy.z, qfy.w };
+		const float vnz[4] = { qnz.x, qnz.y, qnz.z, qnz.w }, vfz[4] = { qfz.x, qfz.y, qfz.z, qfz.w };
+#pragma unroll
+		for (int c = 0; c < 4; ++c)
+		{
+			float tnx = __builtin_fmaf(vnx[c], ax, bx);
+			float tny = __builtin_fmaf(vny[c], ay, by);
+			float tnz = __builtin_fmaf(vnz[c], az, bz);
+			float tfx = __builtin_fmaf(vfx[c], ax, bx);
+			float tfy = __builtin_fmaf(vfy[c], ay, by);
+			float tfz = __builtin_fmaf(vfz[c], az, bz);
+			float t0 = fmaxf(fmaxf(tnx, tny), fmaxf(tnz, tmin));
+			float t1 = fminf(fminf(tfx, tfy), fminf(tfz, tmax));
+			const bool hit = t0 <= t1 * 1.000001f;  // same test as a node step; an empty slot fails it whatever the ray
+			mask = (mask + mask) + (hit ? 1u : 0u);  // one add-with-carry per child
+		}
+	}
+	return mask;
+}
+
+// The reference of the next child in `pend` (not zero), which it removes from the set.
+__device__ __forceinline__ uint32_t pt_entry_next(const uint4 *e, uint32_t &pend)
+{
+	const uint32_t bit = (uint32_t)__builtin_ctz(pend);
+	pend &= pend - 1u;
+	return reinterpret_cast<const uint32_t *>(e + 2)[(uint32_t)(PT_ENTRY_WIDTH - 1) - bit];
+}
+
 template <int kStackLds>
 __device__ __forceinline__ uint32_t pt_stack_pop(int &sp, uint32_t (*sStack)[PT_WAVE], int lane, uint32_t *mySpill,
                                                  uint32_t spillStride)

@@ -15,7 +15,8 @@ best = 1e9
 for rep in range(3):
     t = time.perf_counter(); rt.raytrace(8); rt.synchronize(); best = min(best, (time.perf_counter() - t) / 8)
 st = rt.stats()
-print("%%-28s frame %%.3f ms  %%.0f Mrays/s" %% (os.environ.get("PT_HIP_LIB", "default")[-28:], best * 1e3, st.rays_total / 24 / best / 1e6), flush=True)
+rt.setProfiling(pa.api.PT_PROFILE_TRAVERSAL); rt.resetStats(); rt.resetFrame(); rt.raytrace(1); rt.synchronize(); s2 = rt.stats()
+print("%%-28s frame %%.3f ms  %%.0f Mrays/s   nodes/ray %%.3f tris/ray %%.3f" %% (os.environ.get("PT_HIP_LIB", "default")[-28:], best * 1e3, st.rays_total / 24 / best / 1e6, s2.trav_nodes / s2.rays_total, s2.trav_tris / s2.rays_total), flush=True)
 ''' % root
 for rnd in range(2):
     for v in variants:

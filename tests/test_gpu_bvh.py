@@ -221,29 +221,35 @@ def test_quad_leaves_bit_exact(rt, pa, O, nx, nz, reverse_every, drop_every):
     want, rays = osc.render(view, proj, W, H, frames=2, spp_per_frame=3, max_depth=6, seed=5)
     quads = []
     for builder in (pa.api.PT_ACCEL_BVH4, pa.api.PT_ACCEL_BVH4_PLOC):
-        rt.uploadScene(sc)
-        rt.buildBlas(None, builder)
-        st = rt.stats()
-        quads.append(st.quad_leaves)
-        if drop_every == 2:
-            assert st.quad_leaves == 0  # half of the faces are lone triangles: below the 90 % share
-        rt.resize(W, H)
-        rt.setCamera(view, proj)
-        rt.setParams(spp_per_frame=3, max_depth=6, seed=5)
-        trav = {}
-        for name, mode in (("persistent", 2), ("fused", 0)):
-            rt.setPipeline(mode)
-            for prof in (0, PT_PROFILE_TRAVERSAL):
-                rt.setProfiling(prof)
-                rt.resetFrame()
-                rt.resetStats()
-                rt.raytrace(2)
-                s2 = rt.stats()
-                assert s2.rays_total == rays, (name, prof)
-                assert np.array_equal(bits(rt.readImage()), bits(want)), (name, prof, builder)
-            trav[name] = (s2.trav_nodes, s2.trav_tris, s2.trav_hits)
-        rt.setProfiling(0)
-        assert trav["persistent"] == trav["fused"], trav
+        # with the entry node (default) and without it (then node visits and triangle tests equal the fused pipeline's)
+        for entry_flag in (0, pa.api.PT_ACCEL_NO_ENTRY_NODE):
+            rt.uploadScene(sc)
+            rt.buildBlas(None, builder | entry_flag)
+            st = rt.stats()
+            if entry_flag:
+                quads.append(st.quad_leaves)
+            if drop_every == 2:
+                assert st.quad_leaves == 0  # half of the faces are lone triangles: below the 90 % share
+            rt.resize(W, H)
+            rt.setCamera(view, proj)
+            rt.setParams(spp_per_frame=3, max_depth=6, seed=5)
+            trav = {}
+            for name, mode in (("persistent", 2), ("fused", 0)):
+                rt.setPipeline(mode)
+                for prof in (0, PT_PROFILE_TRAVERSAL):
+                    rt.setProfiling(prof)
+                    rt.resetFrame()
+                    rt.resetStats()
+                    rt.raytrace(2)
+                    s2 = rt.stats()
+                    assert s2.rays_total == rays, (name, prof)
+                    assert np.array_equal(bits(rt.readImage()), bits(want)), (name, prof, builder, entry_flag)
+                trav[name] = (s2.trav_nodes, s2.trav_tris, s2.trav_hits)
+            rt.setProfiling(0)
+            if entry_flag:
+                assert trav["persistent"] == trav["fused"], trav
+            else:
+                assert trav["persistent"][2] == trav["fused"][2], trav
     print("quad leaves (lbvh, ploc):", quads, "of", sc.n_tris // 2, "faces")
     if drop_every != 2:
         assert max(quads) > 0, quads  # at least one builder keeps the faces together

@@ -190,26 +190,32 @@ def test_every_node_source_of_the_path_kernel(rt, pa, O):
     for nx, nz, leaf in [(1, 1, 0), (2, 2, 0), (3, 3, 0), (4, 3, 0), (4, 4, 0), (5, 5, 0), (6, 5, 1), (7, 7, 0), (9, 8, 0)]:
         sc = pa.scenes.grid_mesh(nx, nz, size=2.0, amplitude=0.3)
         osc = O.OracleScene(sc.vertices, sc.indices, sc.materials, sc.mat_indices)
-        rt.uploadScene(sc)
-        rt.buildBlas(None, pa.api.PT_ACCEL_BVH4 | (leaf << 8))
-        nodes = rt.stats().bvh_nodes
-        seen.add("planes" if nodes <= 8 else ("packed" if nodes <= 16 else "global"))
-        rt.resize(W, H)
-        rt.setCamera(view, proj)
-        rt.setParams(spp_per_frame=4, max_depth=6, seed=3)
         want, rays = osc.render(view, proj, W, H, frames=2, spp_per_frame=4, max_depth=6, seed=3)
-        trav = {}
-        for name in ("persistent", "fused"):  # the fused kernel takes the same steps with nodes from memory
-            rt.setPipeline(PIPELINES[name])
-            for prof in (0, PT_PROFILE_TRAVERSAL):  # the counting kernels are instantiations of their own
-                rt.setProfiling(prof)
-                rt.resetFrame()
-                rt.resetStats()
-                rt.raytrace(2)
-                st = rt.stats()
-                assert st.rays_total == rays, (nx, nz, name)
-                assert np.array_equal(bits(rt.readImage()), bits(want)), (nx, nz, nodes, name, prof)
-            trav[name] = (st.trav_nodes, st.trav_tris, st.trav_hits)
-        assert trav["persistent"] == trav["fused"], (nx, nz, nodes, trav)
-        rt.setProfiling(0)
+        # with the entry node (default: the tree top is tested while a ray is staged) and without (every ray starts at
+        # the root: then the persistent kernel takes exactly the fused kernel's steps, with nodes from LDS or memory)
+        for entry_flag in (0, pa.api.PT_ACCEL_NO_ENTRY_NODE):
+            rt.uploadScene(sc)
+            rt.buildBlas(None, pa.api.PT_ACCEL_BVH4 | (leaf << 8) | entry_flag)
+            nodes = rt.stats().bvh_nodes
+            seen.add("planes" if nodes <= 8 else ("packed" if nodes <= 16 else "global"))
+            rt.resize(W, H)
+            rt.setCamera(view, proj)
+            rt.setParams(spp_per_frame=4, max_depth=6, seed=3)
+            trav = {}
+            for name in ("persistent", "fused"):
+                rt.setPipeline(PIPELINES[name])
+                for prof in (0, PT_PROFILE_TRAVERSAL):  # the counting kernels are instantiations of their own
+                    rt.setProfiling(prof)
+                    rt.resetFrame()
+                    rt.resetStats()
+                    rt.raytrace(2)
+                    st = rt.stats()
+                    assert st.rays_total == rays, (nx, nz, name)
+                    assert np.array_equal(bits(rt.readImage()), bits(want)), (nx, nz, nodes, name, prof, entry_flag)
+                trav[name] = (st.trav_nodes, st.trav_tris, st.trav_hits)
+            if entry_flag:
+                assert trav["persistent"] == trav["fused"], (nx, nz, nodes, trav)
+            else:
+                assert trav["persistent"][2] == trav["fused"][2], (nx, nz, nodes, trav)  # the same hits either way
+            rt.setProfiling(0)
     assert seen == {"planes", "packed", "global"}, seen
