@@ -1329,10 +1329,16 @@ hipError_t ptBuildQuadLeaves(const PtNode4 *nodes, uint32_t nNodes, const PtTri4
 namespace
 {
 // One thread: the top of the tree is a handful of nodes.  Starting from the root's children, the inner child with the
-// largest box is replaced by its own children while the list still fits PT_ENTRY_WIDTH; the boxes (dequantised with the
-// fmaf the builder verified them with) are then re-quantised in the frame of their union exactly as k_collapse_level
-// quantises a node -- conservative by the same check -- and stored decoded (pt_wave_traverse.h).
-__global__ void k_entry_node(const PtNode4 *nodes, uint32_t nNodes, uint32_t root, float4 *rec)
+// largest box is replaced by its own children while the list still fits PT_ENTRY_WIDTH.  Boxes: an inner child keeps the
+// box its parent holds for it (dequantised with the fmaf the builder verified it with); a LEAF child gets the exact box of
+// its triangles -- on the 255-step grid of a room-sized node a wall is a slab 1/128 of the room thick that contains the
+// origin of every ray leaving that wall, so each bounce ray would test the quad it starts on; the exact slab is left
+// within t < tmin and the interval test discards it.  All boxes are padded by 2^-18 * max|coordinate| (as the builder pads
+// its leaves), stored relative to the node's origin (rounded outwards): the traversal evaluates
+// t = fma(plane, 1/d, (origin - o)/d), whose rounding errors are relative to the distance travelled (covered by the test's
+// 1e-6 slack) plus 2^-23 of the node's extent (covered by the padding, 2^-18).
+__global__ void k_entry_node(const PtNode4 *nodes, uint32_t nNodes, uint32_t root, const PtTri48 *plane2, const PtQuad64 *quads2,
+                             float4 *rec)
 {
 	if (threadIdx.x != 0 || blockIdx.x != 0) return;
 	constexpr int W = PT_ENTRY_WIDTH, G = W / 4;
@@ -1389,74 +1395,109 @@ __global__ void k_entry_node(const PtNode4 *nodes, uint32_t nNodes, uint32_t roo
 		int k;
 		childrenOf(ref[best], best, k);
 	}
-	float org[3] = { INFINITY, INFINITY, INFINITY }, top[3] = { -INFINITY, -INFINITY, -INFINITY }, scale[3];
+	// inner children first: the lane visits the children last to first, so subtrees are entered after the leaves have
+	// shortened the ray (a node step culls with the best hit so far; a leaf is tested whatever the order)
+	for (int i = 0, at = 0; i < n; ++i)
+		if (!(ref[i] & PT_LEAF_FLAG))
+		{
+			for (int j = i; j > at; --j)
+			{
+				const uint32_t r = ref[j];
+				ref[j] = ref[j - 1];
+				ref[j - 1] = r;
+				for (int a = 0; a < 3; ++a)
+				{
+					float t = lo[j][a];
+					lo[j][a] = lo[j - 1][a];
+					lo[j - 1][a] = t;
+					t = hi[j][a];
+					hi[j][a] = hi[j - 1][a];
+					hi[j - 1][a] = t;
+				}
+			}
+			++at;
+		}
+	float maxAbs = 0.0f;
 	for (int i = 0; i < n; ++i)
-		for (int a = 0; a < 3; ++a)
-		{
-			org[a] = fminf(org[a], lo[i][a]);
-			top[a] = fmaxf(top[a], hi[i][a]);
-		}
-	for (int a = 0; a < 3; ++a)
 	{
-		if (n == 0) org[a] = top[a] = 0.0f;
-		float ext = top[a] - org[a];
-		int e = 1;
-		if (ext > 0.0f)
+		if (ref[i] & PT_LEAF_FLAG)
 		{
-			int ex2;
-			float m = frexpf(ext / 255.0f, &ex2);
-			e = (m == 0.5f ? ex2 - 1 : ex2) + 127;
+			// exact box of the leaf's triangles (plane 2 holds the coordinates in x, y, z order)
+			float l3[3] = { INFINITY, INFINITY, INFINITY }, h3[3] = { -INFINITY, -INFINITY, -INFINITY };
+			auto add = [&](const float *v) {
+				for (int a = 0; a < 3; ++a)
+				{
+					l3[a] = fminf(l3[a], v[a]);
+					h3[a] = fmaxf(h3[a], v[a]);
+				}
+			};
+			const uint32_t first = ref[i] & 0x0FFFFFFFu, cnt = ((ref[i] >> 28) & 7u) + 1u;
+			if (quads2 && ((ref[i] >> 28) & 7u) == PT_LEAF_QUAD)
+			{
+				const PtQuad64 &q = quads2[first];
+				add(q.v0);
+				add(q.v1);
+				add(q.v2);
+				add(q.v3);
+			}
+			else
+				for (uint32_t k = 0; k < cnt; ++k)
+				{
+					const PtTri48 &t = plane2[first + k];
+					add(t.v0);
+					add(t.v1);
+					add(t.v2);
+				}
+			for (int a = 0; a < 3; ++a)
+			{
+				// never larger than what the tree says (the tree's box is what the other pipelines cull with)
+				lo[i][a] = fmaxf(lo[i][a], l3[a]);
+				hi[i][a] = fminf(hi[i][a], h3[a]);
+			}
 		}
-		if (e < 1) e = 1;
-		if (e > 254) e = 254;
-		float sc = __uint_as_float((uint32_t)e << 23);
-		while (e < 254 && !(__builtin_fmaf(255.0f, sc, org[a]) >= top[a]))
-		{
-			++e;
-			sc = __uint_as_float((uint32_t)e << 23);
-		}
-		scale[a] = sc;
+		for (int a = 0; a < 3; ++a) maxAbs = fmaxf(maxAbs, fmaxf(fabsf(lo[i][a]), fabsf(hi[i][a])));
 	}
+	const float pad = maxAbs * 3.814697265625e-06f;  // 2^-18
+	float org[3] = { INFINITY, INFINITY, INFINITY };
+	for (int i = 0; i < n; ++i)
+		for (int a = 0; a < 3; ++a) org[a] = fminf(org[a], lo[i][a]);
 	float *out = reinterpret_cast<float *>(rec);
 	uint32_t *outU = reinterpret_cast<uint32_t *>(rec);
-	out[0] = org[0];
-	out[1] = org[1];
-	out[2] = org[2];
-	out[3] = scale[0];
-	out[4] = scale[1];
-	out[5] = scale[2];
-	outU[6] = (uint32_t)n;
-	outU[7] = 0u;
+	for (int a = 0; a < 3; ++a) out[a] = n ? org[a] : 0.0f;
+	out[3] = 0.0f;
+	outU[4] = (uint32_t)n;
+	outU[5] = outU[6] = outU[7] = 0u;
 	for (int i = 0; i < W; ++i)
 	{
 		outU[8 + i] = i < n ? ref[i] : PT_EMPTY_CHILD;
 		for (int a = 0; a < 3; ++a)
 		{
-			float ql = INFINITY, qh = -INFINITY;
+			float pl = INFINITY, ph = -INFINITY;
 			if (i < n)
 			{
-				ql = floorf((lo[i][a] - org[a]) / scale[a]);
-				ql = fminf(fmaxf(ql, 0.0f), 255.0f);
-				while (ql > 0.0f && __builtin_fmaf(ql, scale[a], org[a]) > lo[i][a]) ql -= 1.0f;
-				qh = ceilf((hi[i][a] - org[a]) / scale[a]);
-				qh = fminf(fmaxf(qh, 0.0f), 255.0f);
-				while (qh < 255.0f && __builtin_fmaf(qh, scale[a], org[a]) < hi[i][a]) qh += 1.0f;
+				// relative to the origin, padded, and one more step outwards for the rounding of the two operations
+				pl = (lo[i][a] - pad) - org[a];
+				ph = (hi[i][a] + pad) - org[a];
+				pl = nextafterf(pl, -INFINITY);
+				ph = nextafterf(ph, INFINITY);
 			}
-			out[4 * (2 + G) + (0 + a) * W + i] = ql;
-			out[4 * (2 + G) + (3 + a) * W + i] = qh;
+			out[4 * (2 + G) + (0 + a) * W + i] = pl;
+			out[4 * (2 + G) + (3 + a) * W + i] = ph;
 		}
 	}
 }
 }  // namespace
 
-hipError_t ptBuildEntryNode(const PtNode4 *nodes, uint32_t nNodes, uint32_t root, uint4 **rec, hipStream_t stream)
+hipError_t ptBuildEntryNode(const PtNode4 *nodes, uint32_t nNodes, uint32_t root, const PtTri48 *tris, uint32_t nTris,
+                            const PtQuad64 *quads, uint32_t nQuads, uint4 **rec, hipStream_t stream)
 {
 	*rec = nullptr;
 	if (!nNodes || root >= nNodes) return hipSuccess;
 	uint4 *d = nullptr;
 	hipError_t e = hipMalloc(&d, sizeof(uint4) * PT_ENTRY_REC);
 	if (e != hipSuccess) return e;
-	k_entry_node<<<1, 64, 0, stream>>>(nodes, nNodes, root, reinterpret_cast<float4 *>(d));
+	k_entry_node<<<1, 64, 0, stream>>>(nodes, nNodes, root, tris + 2 * (size_t)nTris, nQuads ? quads + 2 * (size_t)nQuads : nullptr,
+	                                   reinterpret_cast<float4 *>(d));
 	e = hipGetLastError();
 	if (e == hipSuccess) e = hipStreamSynchronize(stream);
 	if (e != hipSuccess)

@@ -255,10 +255,11 @@ __device__ __forceinline__ void pt_node_step(const PtSceneDev &sc, const PtLaneR
 // The top of the tree flattened into ONE wide node (pt_build.h, ptBuildEntryNode) that k_paths tests in its STAGING phase,
 // where all 64 lanes hold a fresh ray -- the first node visits of every ray at full lane utilisation instead of inside the
 // traversal loop at ~0.68, and as one wide step instead of two or three 4-wide ones (Cornell: root + the two room-sized
-// nodes every ray is inside = 3.04 visits of 105 instructions -> one 8-wide test).  Record, in 16-byte units (W = width):
-//   [0] origin.xyz, scaleX   [1] scaleY, scaleZ, children, -   [2 .. 2+W/4) child references
-//   then six plane arrays of W floats: lo x, lo y, lo z, hi x, hi y, hi z -- the quantised planes as floats, as in the
-//   decoded node records above (same fma, near/far picked by address, an empty slot is lo = +inf / hi = -inf).
+// nodes every ray is inside = 3.04 visits of 105 instructions -> one 16-wide test).  Record, in 16-byte units (W = width):
+//   [0] origin.xyz, -   [1] children, -, -, -   [2 .. 2+W/4) child references
+//   then six plane arrays of W floats: lo x, lo y, lo z, hi x, hi y, hi z -- distances of the planes from the origin (the
+//   fma of the decoded node records above with a scale of one, near/far picked by address, an empty slot is lo = +inf /
+//   hi = -inf).  Leaf children carry the exact (padded) boxes of their triangles, not the node grid's (pt_bvh_build.hip).
 // The children keep their ordinary references (leaves, quad leaves, inner nodes of the ordinary array), so what follows the
 // entry test is the ordinary traversal; the flattened nodes stay in the array for rays that do not use the entry node.
 // (PT_ENTRY_WIDTH, PT_ENTRY_REC: pt_device_common.h)
@@ -270,9 +271,9 @@ __device__ __forceinline__ uint32_t pt_entry_test(const uint4 *e, const PtLaneRa
 {
 	constexpr int W = PT_ENTRY_WIDTH, G = W / 4;
 	const float4 *rec = reinterpret_cast<const float4 *>(e);
-	const float4 h0 = rec[0], h1 = rec[1];
+	const float4 h0 = rec[0];
 	const bool negx = ray.kpack & 64u, negy = ray.kpack & 128u, negz = ray.kpack & 256u;
-	const float ax = h0.w * ray.ix, ay = h1.x * ray.iy, az = h1.y * ray.iz;
+	const float ax = ray.ix, ay = ray.iy, az = ray.iz;  // planes are distances from the origin, not grid indices
 	const float bx = (h0.x - ray.ox) * ray.ix, by = (h0.y - ray.oy) * ray.iy, bz = (h0.z - ray.oz) * ray.iz;
 	const float4 *planes = rec + 2 + G;
 	const int nx = negx ? 3 * G : 0, ny = negy ? 3 * G : 0, nz = negz ? 3 * G : 0;
