@@ -345,7 +345,10 @@ __global__ void __launch_bounds__(PT_WAVE) PT_PATHS_OCCUPANCY k_paths(PtPathsArg
 		{
 			PT_T_MARK(PT_T_RETIRE)
 			// ------------------------------------------------------------------ C: retire finished lanes ----
-			bool fin = (q != kNoPath) && (cur == PT_TRAVERSAL_DONE);
+			// (a ray that hit nothing is finished for good -- rmiss adds nothing and ends the path -- and is not parked)
+			const bool ended = (q != kNoPath) && (cur == PT_TRAVERSAL_DONE);
+			if (ended && best.prim == PT_NO_HIT) q = kNoPath;
+			bool fin = ended && best.prim != PT_NO_HIT;
 			unsigned long long fm = __ballot(fin);
 			if (fm)
 			{
