@@ -73,6 +73,7 @@ struct pt_ctx
 	PtBuildOutput accel;
 	PtQuadOutput quadAccel;  // quad leaves + the node array that refers to them (persistent pipeline only)
 	uint4 *dEntry = nullptr;  // entry node of the persistent pipeline (flattened tree top, pt_wave_traverse.h) or nullptr
+	bool entryFlat = false;   // the entry node holds every leaf of the scene
 	double buildMs = 0.0;
 	uint64_t accelBytes = 0, accelBytesUncompacted = 0;  // acceleration-structure memory after / before compaction
 	// two-level scenes (pt_set_instances): 24 floats per instance (object-to-world 3x4, world-to-object 3x4)
@@ -168,6 +169,7 @@ void freeAccel(pt_ctx *c)
 	c->quadAccel = PtQuadOutput();
 	hipFree(c->dEntry);
 	c->dEntry = nullptr;
+	c->entryFlat = false;
 	c->haveAccel = false;
 }
 
@@ -677,7 +679,8 @@ extern "C" int pt_build_accel(pt_ctx *c, int flags) try
 	{
 		// the tree top as one wide node that k_paths tests while it stages a ray (of the node array k_paths traverses)
 		hipError_t ee = ptBuildEntryNode(c->quadAccel.nQuads ? c->quadAccel.nodes : c->accel.nodes, c->accel.nNodes, 0u, c->accel.tris,
-		                                 c->accel.nTris, c->quadAccel.quads, c->quadAccel.nQuads, &c->dEntry, c->stream);
+		                                 c->accel.nTris, c->quadAccel.quads, c->quadAccel.nQuads, &c->dEntry, &c->entryFlat, c->stream);
+		if (getenv("PT_NO_FLAT")) c->entryFlat = false;
 		if (ee != hipSuccess)
 		{
 			freeAccel(c);
@@ -1031,6 +1034,7 @@ int renderPersistent(pt_ctx *c, int n, bool noAlloc = false)
 		pa.nInst = c->tlasDepth ? c->nInst : 0;
 		pa.tlasRoot = c->tlasRoot;
 		pa.entry = pa.nInst ? nullptr : c->dEntry;
+		pa.entryFlat = c->entryFlat ? 1u : 0u;
 		ptLaunchPaths(pa, waves, statsKernel, s);
 		if (e1) hipEventRecord(e1, s);
 		ptLaunchAccumulateItems(rad, tile, c->W, (uint32_t)c->spp, c->image, frame0, batch, c->accumMode, s);

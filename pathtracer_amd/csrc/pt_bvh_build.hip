@@ -1466,7 +1466,10 @@ __global__ void k_entry_node(const PtNode4 *nodes, uint32_t nNodes, uint32_t roo
 	for (int a = 0; a < 3; ++a) out[a] = n ? org[a] : 0.0f;
 	out[3] = 0.0f;
 	outU[4] = (uint32_t)n;
-	outU[5] = outU[6] = outU[7] = 0u;
+	uint32_t nInner = 0;
+	for (int i = 0; i < n; ++i) nInner += (ref[i] & PT_LEAF_FLAG) ? 0u : 1u;
+	outU[5] = nInner;
+	outU[6] = outU[7] = 0u;
 	for (int i = 0; i < W; ++i)
 	{
 		outU[8 + i] = i < n ? ref[i] : PT_EMPTY_CHILD;
@@ -1489,9 +1492,10 @@ __global__ void k_entry_node(const PtNode4 *nodes, uint32_t nNodes, uint32_t roo
 }  // namespace
 
 hipError_t ptBuildEntryNode(const PtNode4 *nodes, uint32_t nNodes, uint32_t root, const PtTri48 *tris, uint32_t nTris,
-                            const PtQuad64 *quads, uint32_t nQuads, uint4 **rec, hipStream_t stream)
+                            const PtQuad64 *quads, uint32_t nQuads, uint4 **rec, bool *flat, hipStream_t stream)
 {
 	*rec = nullptr;
+	*flat = false;
 	if (!nNodes || root >= nNodes) return hipSuccess;
 	uint4 *d = nullptr;
 	hipError_t e = hipMalloc(&d, sizeof(uint4) * PT_ENTRY_REC);
@@ -1499,6 +1503,8 @@ hipError_t ptBuildEntryNode(const PtNode4 *nodes, uint32_t nNodes, uint32_t root
 	k_entry_node<<<1, 64, 0, stream>>>(nodes, nNodes, root, tris + 2 * (size_t)nTris, nQuads ? quads + 2 * (size_t)nQuads : nullptr,
 	                                   reinterpret_cast<float4 *>(d));
 	e = hipGetLastError();
+	uint32_t head[8] = {};
+	if (e == hipSuccess) e = hipMemcpyAsync(head, d, sizeof(head), hipMemcpyDeviceToHost, stream);
 	if (e == hipSuccess) e = hipStreamSynchronize(stream);
 	if (e != hipSuccess)
 	{
@@ -1506,5 +1512,6 @@ hipError_t ptBuildEntryNode(const PtNode4 *nodes, uint32_t nNodes, uint32_t root
 		return e;
 	}
 	*rec = d;
+	*flat = head[4] != 0u && head[5] == 0u;  // children, inner children
 	return hipSuccess;
 }

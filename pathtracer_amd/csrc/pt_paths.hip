@@ -145,19 +145,32 @@ enum
 // a leaf reference is an instance index: the lane saves its prepared world ray in LDS, transforms the ray with the
 // instance's world-to-object matrix (direction NOT renormalised: t means the same in both spaces), pushes
 // PT_INSTANCE_END and descends into the bottom-level tree; popping the marker restores the world ray.
-// kEntry: the scene has an entry node (a.entry; pt_wave_traverse.h): the staging phase tests every fresh ray against it
-// and hands the lane that takes the ray the set of children it hits; the lane visits them one after the other.
-template <bool kStats, bool kInst, int kNodeMode, bool kEntry>
+// kEntryMode: PT_ENTRY_NONE, or the scene has an entry node (a.entry; pt_wave_traverse.h): the staging phase tests every
+// fresh ray against it and hands the lane that takes the ray the set of children it hits; the lane visits them one after
+// the other.  PT_ENTRY_FLAT: every child of the entry node is a leaf (a scene of at most PT_ENTRY_WIDTH leaves, the Cornell
+// box's 16 quads) -- there is no tree left to traverse, so no stack and no node step; the staging phase also tests the
+// FIRST leaf the ray's box test selects, at full lane utilisation, and only a ray with further candidates (one in three
+// on Cornell) is handed to a lane at all: the others go straight to the shading ring, or nowhere when they hit nothing.
+enum
+{
+	PT_ENTRY_NONE = 0,
+	PT_ENTRY_TREE = 1,
+	PT_ENTRY_FLAT = 2
+};
+template <bool kStats, bool kInst, int kNodeMode, int kEntryMode>
 __global__ void __launch_bounds__(PT_WAVE) PT_PATHS_OCCUPANCY k_paths(PtPathsArgs a)
 {
+	constexpr bool kEntry = kEntryMode != PT_ENTRY_NONE, kFlat = kEntryMode == PT_ENTRY_FLAT;
 	static_assert(!(kEntry && kInst), "the entry node is built for single-level scenes");
+	static_assert(!kFlat || kNodeMode == PT_NODES_GLOBAL, "a flat scene has no nodes to copy");
 	constexpr bool kTiny = kEntry && kNodeMode != PT_NODES_GLOBAL;
 	constexpr int kStackLds = kTiny ? kStackLdsTiny : kStackLdsFull;
 	constexpr int kDoneRing = kTiny ? kDoneRingTiny : kDoneRingFull;
 	constexpr int kInEntry = kInFields;  // entry children the ray hits (kEntry) / first row of the world direction (kInst)
 	constexpr int kInDir = kInFields;
-	__shared__ uint32_t sStack[kStackLds][PT_WAVE];
-	__shared__ uint32_t sIn[kInFields + (kInst ? 3 : 0) + (kEntry ? 1 : 0)][PT_WAVE];
+	constexpr int kInBest = kInFields + 1;  // kFlat: best hit so far (t, prim, V, W, det) of a ray that was tested while staged
+	__shared__ uint32_t sStack[kFlat ? 1 : kStackLds][PT_WAVE];
+	__shared__ uint32_t sIn[kInFields + (kInst ? 3 : 0) + (kEntry ? 1 : 0) + (kFlat ? 5 : 0)][PT_WAVE];
 	__shared__ uint32_t sDone[kDoneFields + (kInst ? 1 : 0)][kDoneRing];
 	__shared__ uint4 sEntry[kEntry ? PT_ENTRY_REC : 1];
 	if (kEntry)
@@ -302,37 +315,94 @@ __global__ void __launch_bounds__(PT_WAVE) PT_PATHS_OCCUPANCY k_paths(PtPathsArg
 		ringCount += popcWave(am);
 	};
 
-	// Writes lane's prepared ray into the staging area.
-	auto stage = [&](float3x o, float3x d, uint32_t depth, uint32_t pq) {
-		PtLaneRay pr = pt_prepare_ray<true>(o, d);  // every lane of the staging batch is here: the shared-reciprocal form
-		sIn[0][lane] = __float_as_uint(pr.ox);
-		sIn[1][lane] = __float_as_uint(pr.oy);
-		sIn[2][lane] = __float_as_uint(pr.oz);
-		sIn[3][lane] = __float_as_uint(pr.ix);
-		sIn[4][lane] = __float_as_uint(pr.iy);
-		sIn[5][lane] = __float_as_uint(pr.iz);
-		sIn[6][lane] = __float_as_uint(pr.Sx);
-		sIn[7][lane] = __float_as_uint(pr.Sy);
-		sIn[8][lane] = __float_as_uint(pr.Sz);
-		sIn[9][lane] = pr.kpack | (depth << 16);
-		sIn[10][lane] = pq;
-		if (kEntry)
+	// Prepares the rays of a staging batch (lanes with `valid`; every lane of the wave calls) and writes them into the
+	// staging area; returns how many rays wait there for a lane.
+	auto stage = [&](bool valid, float3x o, float3x d, uint32_t depth, uint32_t pq) -> uint32_t {
+		if (!kFlat)
 		{
-			sIn[kInEntry][lane] = pt_entry_test(sEntry, pr, tmin, tmax);
-			if (kStats) ++nodeFetches;  // one (wide) node visit
+			if (valid)
+			{
+				PtLaneRay pr = pt_prepare_ray<true>(o, d);  // every lane of the staging batch is here: the shared-reciprocal form
+				sIn[0][lane] = __float_as_uint(pr.ox);
+				sIn[1][lane] = __float_as_uint(pr.oy);
+				sIn[2][lane] = __float_as_uint(pr.oz);
+				sIn[3][lane] = __float_as_uint(pr.ix);
+				sIn[4][lane] = __float_as_uint(pr.iy);
+				sIn[5][lane] = __float_as_uint(pr.iz);
+				sIn[6][lane] = __float_as_uint(pr.Sx);
+				sIn[7][lane] = __float_as_uint(pr.Sy);
+				sIn[8][lane] = __float_as_uint(pr.Sz);
+				sIn[9][lane] = pr.kpack | (depth << 16);
+				sIn[10][lane] = pq;
+				if (kEntry)
+				{
+					sIn[kInEntry][lane] = pt_entry_test(sEntry, pr, tmin, tmax);
+					if (kStats) ++nodeFetches;  // one (wide) node visit
+				}
+				if (kInst)
+				{
+					sIn[kInDir + 0][lane] = __float_as_uint(d.x);
+					sIn[kInDir + 1][lane] = __float_as_uint(d.y);
+					sIn[kInDir + 2][lane] = __float_as_uint(d.z);
+				}
+			}
+			return popcWave(__ballot(valid));  // valid lanes are 0 .. n-1
 		}
-		if (kInst)
+		// flat scene: box test and the first leaf here, with all 64 lanes; then the ray is finished (hit: parked for the
+		// shading pass; nothing hit: gone) or goes -- ballot-packed -- to the staging area with what it has found so far
+		PtLaneRay pr = {};
+		PtBest b = { tmax, PT_NO_HIT, 0.0f, 0.0f, 1.0f };
+		uint32_t m = 0;
+		if (valid)
 		{
-			sIn[kInDir + 0][lane] = __float_as_uint(d.x);
-			sIn[kInDir + 1][lane] = __float_as_uint(d.y);
-			sIn[kInDir + 2][lane] = __float_as_uint(d.z);
+			pr = pt_prepare_ray<true>(o, d);
+			m = pt_entry_test(sEntry, pr, tmin, tmax);
+			if (kStats) ++nodeFetches;
+			if (m)
+			{
+				const uint32_t ref = pt_entry_next(sEntry, m);
+				if (kStats) ++leafVisits;
+				pt_leaf_test<true>(sc, pr, tmin, b, ref, triTests);
+			}
 		}
+		const bool more = valid && m != 0u, parked = valid && m == 0u && b.prim != PT_NO_HIT;
+		const unsigned long long mm = __ballot(more), hm = __ballot(parked);
+		if (parked)
+		{
+			const uint32_t e = pt_ring_at<kDoneRing>(pt_ring_at<kDoneRing>(doneHead + doneCount) + popc64(hm & lanesBelow));
+			sDone[0][e] = __float_as_uint(b.V);
+			sDone[1][e] = __float_as_uint(b.W);
+			sDone[2][e] = __float_as_uint(b.det);
+			sDone[3][e] = b.prim;
+			sDone[4][e] = pq;
+			sDone[5][e] = pr.kpack | (depth << 16);
+		}
+		doneCount += popcWave(hm);  // <= 63 before (the caller shades as soon as 64 are parked), so <= 127 now
+		if (more)
+		{
+			const uint32_t r = popc64(mm & lanesBelow);
+			sIn[0][r] = __float_as_uint(pr.ox);
+			sIn[1][r] = __float_as_uint(pr.oy);
+			sIn[2][r] = __float_as_uint(pr.oz);
+			sIn[6][r] = __float_as_uint(pr.Sx);
+			sIn[7][r] = __float_as_uint(pr.Sy);
+			sIn[8][r] = __float_as_uint(pr.Sz);
+			sIn[9][r] = pr.kpack | (depth << 16);
+			sIn[10][r] = pq;
+			sIn[kInEntry][r] = m;
+			sIn[kInBest + 0][r] = __float_as_uint(b.t);
+			sIn[kInBest + 1][r] = b.prim;
+			sIn[kInBest + 2][r] = __float_as_uint(b.V);
+			sIn[kInBest + 3][r] = __float_as_uint(b.W);
+			sIn[kInBest + 4][r] = __float_as_uint(b.det);
+		}
+		return popcWave(mm);
 	};
 
 	for (;;)
 	{
 		PT_T_MARK(PT_T_LOOP)
-		if (kEntry && cur == PT_TRAVERSAL_DONE && pend != 0u)
+		if (kEntry && !kFlat && cur == PT_TRAVERSAL_DONE && pend != 0u)
 		{
 			// the subtree of one entry child is finished (the sentinel was popped): on to the next child the ray hits
 			cur = pt_entry_next(sEntry, pend);
@@ -389,19 +459,22 @@ __global__ void __launch_bounds__(PT_WAVE) PT_PATHS_OCCUPANCY k_paths(PtPathsArg
 			{
 				if (inPos == inCount)
 				{
-					uint32_t n = 0;
+					uint32_t n = 0, staged = 0;
 					if (ringCount >= PT_WAVE || (genDone && ringCount > 0))
 					{
 						// continue paths of this wave: the next (up to) 64 survivors
 						PT_T_MARK(PT_T_RING)
 						n = ringCount < PT_WAVE ? ringCount : PT_WAVE;
 						__syncthreads();  // staging contents consumed; ring stores of earlier flushes complete
+						float4 ro = make_float4(0.0f, 0.0f, 0.0f, 0.0f), rd = ro;
 						if ((uint32_t)lane < n)
 						{
 							uint32_t slot = (ringHead + lane) & (PT_PATHS_RING - 1);
-							float4 ro = ringO[slot], rd = ringD[slot];
-							stage({ ro.x, ro.y, ro.z }, { rd.x, rd.y, rd.z }, __float_as_uint(ro.w), __float_as_uint(rd.w));
+							ro = ringO[slot];
+							rd = ringD[slot];
 						}
+						staged = stage((uint32_t)lane < n, { ro.x, ro.y, ro.z }, { rd.x, rd.y, rd.z }, __float_as_uint(ro.w),
+						               __float_as_uint(rd.w));
 						ringHead += n;
 						ringCount -= n;
 					}
@@ -466,6 +539,8 @@ __global__ void __launch_bounds__(PT_WAVE) PT_PATHS_OCCUPANCY k_paths(PtPathsArg
 						}
 						n = popcWave(__ballot(genValid));  // valid lanes are 0 .. n-1 (only the last group is partial)
 						__syncthreads();
+						float3x go = { 0, 0, 0 }, gd = { 0, 0, 1 };
+						uint32_t gq = 0;
 						if (genValid)
 						{
 							float r1 = pt_rnd(genSeed);
@@ -484,8 +559,11 @@ __global__ void __launch_bounds__(PT_WAVE) PT_PATHS_OCCUPANCY k_paths(PtPathsArg
 							// draws, while the raygen-local seed continues from the same state for the next sample
 							a.state[pq] = make_float4(1.0f, 1.0f, 1.0f, __uint_as_float(genSeed));
 							a.rad[pq] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-							stage(o, d, 0u, pq);
+							go = o;
+							gd = d;
+							gq = pq;
 						}
+						staged = stage(genValid, go, gd, 0u, gq);
 						if (n == 0) continue;
 					}
 					else
@@ -501,9 +579,20 @@ __global__ void __launch_bounds__(PT_WAVE) PT_PATHS_OCCUPANCY k_paths(PtPathsArg
 						break;
 					}
 					__syncthreads();
-					inCount = n;
+					inCount = staged;
 					inPos = 0;
 					raysFetched += n;
+					if (kFlat)
+					{
+						// rays that were finished while staged are parked already: shade as soon as a full batch waits
+						if (doneCount >= PT_WAVE)
+						{
+							PT_T_MARK(PT_T_FLUSH)
+							flush(PT_WAVE);
+							__syncthreads();
+						}
+						if (staged == 0) continue;  // none of the batch needs a lane: stage the next one
+					}
 					PT_T_MARK(PT_T_TAKE)
 				}
 				uint32_t avail = inCount - inPos, want = popcWave(idle);
@@ -550,6 +639,14 @@ __global__ void __launch_bounds__(PT_WAVE) PT_PATHS_OCCUPANCY k_paths(PtPathsArg
 						pend = sIn[kInEntry][s];
 						cur = pend ? pt_entry_next(sEntry, pend) : PT_TRAVERSAL_DONE;
 					}
+					if (kFlat)
+					{
+						best.t = __uint_as_float(sIn[kInBest + 0][s]);
+						best.prim = sIn[kInBest + 1][s];
+						best.V = __uint_as_float(sIn[kInBest + 2][s]);
+						best.W = __uint_as_float(sIn[kInBest + 3][s]);
+						best.det = __uint_as_float(sIn[kInBest + 4][s]);
+					}
 				}
 				inPos += n;
 				idle &= ~__ballot(take);
@@ -571,6 +668,20 @@ __global__ void __launch_bounds__(PT_WAVE) PT_PATHS_OCCUPANCY k_paths(PtPathsArg
 		}
 
 		// ------------------------------------------------------------------ B: traverse ----
+		if (kFlat)
+		{
+			// every lane that holds a ray is at a leaf: test it, then on to the next leaf the ray's box test selected
+			PT_T_MARK(PT_T_LEAF)
+			const PtLaneRay fray = { ox, oy, oz, 0.0f, 0.0f, 0.0f, Sx, Sy, Sz, kpack };
+			if (kStats) ++leafSteps;
+			if (cur != PT_TRAVERSAL_DONE)
+			{
+				if (kStats) ++leafVisits;
+				pt_leaf_test<true>(sc, fray, tmin, best, cur, triTests);
+				cur = pend ? pt_entry_next(sEntry, pend) : PT_TRAVERSAL_DONE;
+			}
+			continue;
+		}
 		// One step for the LARGER of the two groups (majority-phase stepping, see pt_bounce.hip).
 		PT_T_MARK(PT_T_LOOP)
 		const unsigned long long nodeLanes = __ballot(!(cur & PT_LEAF_FLAG));
@@ -763,13 +874,18 @@ void ptLaunchPaths(const PtPathsArgs &args, uint32_t waves, bool stats, hipStrea
 	{                                                                                                \
 		if (args.entry && !(inst))                                                                   \
 		{                                                                                            \
-			if (stats) k_paths<true, false, mode, true><<<waves, PT_WAVE, 0, s>>>(args);             \
-			else k_paths<false, false, mode, true><<<waves, PT_WAVE, 0, s>>>(args);                  \
+			if (stats) k_paths<true, false, mode, PT_ENTRY_TREE><<<waves, PT_WAVE, 0, s>>>(args);    \
+			else k_paths<false, false, mode, PT_ENTRY_TREE><<<waves, PT_WAVE, 0, s>>>(args);         \
 		}                                                                                            \
-		else if (stats) k_paths<true, inst, mode, false><<<waves, PT_WAVE, 0, s>>>(args);            \
-		else k_paths<false, inst, mode, false><<<waves, PT_WAVE, 0, s>>>(args);                      \
+		else if (stats) k_paths<true, inst, mode, PT_ENTRY_NONE><<<waves, PT_WAVE, 0, s>>>(args);    \
+		else k_paths<false, inst, mode, PT_ENTRY_NONE><<<waves, PT_WAVE, 0, s>>>(args);              \
 	}
 	if (args.nInst) PT_LAUNCH(true, PT_NODES_GLOBAL)
+	else if (args.entry && args.entryFlat)
+	{
+		if (stats) k_paths<true, false, PT_NODES_GLOBAL, PT_ENTRY_FLAT><<<waves, PT_WAVE, 0, s>>>(args);
+		else k_paths<false, false, PT_NODES_GLOBAL, PT_ENTRY_FLAT><<<waves, PT_WAVE, 0, s>>>(args);
+	}
 	else if (nNodes && nNodes <= PT_LDS_NODES_PLANES && !ldsOff && !planesOff) PT_LAUNCH(false, PT_NODES_PLANES)
 	else if (nNodes && nNodes <= PT_LDS_NODES_PACKED && !ldsOff) PT_LAUNCH(false, PT_NODES_PACKED)
 	else PT_LAUNCH(false, PT_NODES_GLOBAL)

@@ -91,6 +91,7 @@ struct PtPathsArgs
 	const float *instances;
 	uint32_t nInst, tlasRoot;
 	const uint4 *entry;  // entry node (PT_ENTRY_REC 16-byte units, pt_wave_traverse.h) or nullptr: every ray starts at the root
+	uint32_t entryFlat;  // every child of the entry node is a leaf: the whole scene is that one node
 };
 void ptLaunchPaths(const PtPathsArgs &args, uint32_t waves, bool stats, hipStream_t s);
 void ptLaunchStoreCamera(const PtCamera &cam, PtCamera *dst, hipStream_t s);

@@ -338,19 +338,14 @@ __device__ __forceinline__ void pt_stack_push(uint32_t v, int &sp, uint32_t (*sS
 // curInst / bestInst: instance the lane is inside and instance of the best hit (two-level scenes; ties at equal t
 // go to the lower instance index, then the lower primitive id).  Single-level callers pass 0 and a dummy.
 // kQuads: the tree may hold quad leaf references (PtQuad64; k_paths on scenes made of quad faces).
-template <int kStackLds, bool kQuads = false>
-__device__ __forceinline__ void pt_leaf_step(const PtSceneDev &sc, const PtLaneRay &ray, float tmin, PtBest &best,
-                                             uint32_t &cur, int &sp, uint32_t (*sStack)[PT_WAVE], int lane,
-                                             uint32_t *mySpill, uint32_t spillStride, uint32_t &triTests,
-                                             uint32_t curInst = 0u, uint32_t *bestInst = nullptr)
+// The triangles (or the quad) of leaf reference `cur` against the ray: the leaf step without its stack pop.
+template <bool kQuads = false>
+__device__ __forceinline__ void pt_leaf_test(const PtSceneDev &sc, const PtLaneRay &ray, float tmin, PtBest &best,
+                                             const uint32_t cur, uint32_t &triTests, uint32_t curInst = 0u,
+                                             uint32_t *bestInst = nullptr)
 {
 	const float ox = ray.ox, oy = ray.oy, oz = ray.oz, Sx = ray.Sx, Sy = ray.Sy, Sz = ray.Sz;
 	const uint32_t kpack = ray.kpack;
-	// the next entry is needed whatever the triangles say: read it first
-	--sp;
-	uint32_t next = sp < kStackLds ? sStack[sp][lane]
-	                               : (sp < kStackLds + PT_SPILL_STACK ? mySpill[(size_t)(sp - kStackLds) * spillStride]
-	                                                                  : PT_EMPTY_CHILD);
 	// Second half of the Woop/Benthin/Wald watertight test (pt_tri_test without the selects), in two parts.
 	// inside(): the edge functions U, V, W of the sheared vertices (Ax, Ay) (Bx, By) (Cx, Cy) are recomputed in double
 	// precision when one of them is zero; true when the ray passes inside the triangle (det = U + V + W, not zero).
@@ -453,5 +448,19 @@ __device__ __forceinline__ void pt_leaf_step(const PtSceneDev &sc, const PtLaneR
 			if (inA && inB) accept(UB, VB, WB, detB, P0z, P2z, P3z, prims.y);
 		}
 	}
+}
+
+template <int kStackLds, bool kQuads = false>
+__device__ __forceinline__ void pt_leaf_step(const PtSceneDev &sc, const PtLaneRay &ray, float tmin, PtBest &best,
+                                             uint32_t &cur, int &sp, uint32_t (*sStack)[PT_WAVE], int lane,
+                                             uint32_t *mySpill, uint32_t spillStride, uint32_t &triTests,
+                                             uint32_t curInst = 0u, uint32_t *bestInst = nullptr)
+{
+	// the next entry is needed whatever the triangles say: read it first
+	--sp;
+	uint32_t next = sp < kStackLds ? sStack[sp][lane]
+	                               : (sp < kStackLds + PT_SPILL_STACK ? mySpill[(size_t)(sp - kStackLds) * spillStride]
+	                                                                  : PT_EMPTY_CHILD);
+	pt_leaf_test<kQuads>(sc, ray, tmin, best, cur, triTests, curInst, bestInst);
 	cur = next;
 }
