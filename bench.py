@@ -238,8 +238,11 @@ def main():
     tris_per_ray = ts.trav_tris / rays_stat
     p_hit = ts.trav_hits / rays_stat
     divergence = None
-    if ts.trav_node_steps and ts.trav_leaf_steps:
-        divergence = {"node_step_lane_util": round(ts.trav_nodes / (64.0 * ts.trav_node_steps), 4),
+    if ts.trav_leaf_steps:
+        # steps of the traversal loop only: with an entry node (pt_wave_traverse.h) a ray's first node visit -- on a flat
+        # scene like the Cornell box also its first leaf test -- happens in the staging phase, with all 64 lanes
+        divergence = {"node_step_lane_util": (round(ts.trav_nodes / (64.0 * ts.trav_node_steps), 4)
+                                              if ts.trav_node_steps else None),
                       "leaf_step_lane_util": round(ts.trav_leaf_visits / (64.0 * ts.trav_leaf_steps), 4),
                       "node_steps_per_64_rays": round(64.0 * ts.trav_node_steps / rays_stat, 3),
                       "leaf_steps_per_64_rays": round(64.0 * ts.trav_leaf_steps / rays_stat, 3),
