@@ -3,14 +3,21 @@
 // without the window: loads an OBJ, renders N frames, writes the accumulation image.
 //
 //   pt_render scene.obj [-w 800] [-h 600] [-spp 10] [-frames 100] [-depth 20] [-seed 0] [-tex map.png]
-//             [-o out.pfm|out.ppm|out.png]
+//             [-o out.pfm|out.ppm|out.png] [-gpus G] [-devices 0,1,..] [-split streams|tiles]
 //
 // Defaults are the reference's constants (VulkanUtils.h:11-15, raytrace.rgen:22-23).
+// -gpus G: one host thread and one context per GPU (the rule of pathtracer_amd/multigpu.py): with
+// `streams` GPU r renders the global frames r, r+G, ... (frames rounded up to a multiple of G), with `tiles` every GPU renders
+// all frames of its own column strip; each accumulates raw sums (PT_ACCUM_SUM) against its own copy of the scene and BVH, and
+// the host adds the G images in rank order and divides by the number of frames -- no exchange between the GPUs.  -devices
+// names the ordinals (default 0 .. G-1; the same ordinal may appear twice, which is how one GPU rehearses the path).
 #include <chrono>
+#include <cmath>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "pt_hip.h"
@@ -26,69 +33,195 @@
 		}                                                                  \
 	} while (0)
 
+struct Job
+{
+	const PtSceneData *sd = nullptr;
+	std::string texPath;
+	uint32_t W = 800, H = 600, seed = 0;
+	int spp = 10, depth = 20;
+	int frames = 100;       // frames THIS context renders
+	uint32_t first = 0, stride = 1;
+	uint32_t tile[4] = { 0, 0, 0, 0 };  // w == 0: whole image
+	int accum = PT_ACCUM_MEAN;
+	int device = 0;
+	// results
+	std::vector<float> image;
+	PtStats stats = {};
+	double seconds = 0.0;
+	int rc = EXIT_SUCCESS;
+};
+
+// post.frag + sRGB attachment on the host (the library's k_srgb8 on an image that exists only here: the sum of G GPUs')
+static void linearToSrgb8(const float *rgba, size_t nPixels, uint8_t *out)
+{
+	for (size_t i = 0; i < 4 * nPixels; ++i)
+	{
+		float x = rgba[i];
+		if (!(x > 0.0f)) x = 0.0f;
+		if (x > 1.0f) x = 1.0f;
+		float e = x;
+		if ((i & 3) < 3) e = x <= 0.0031308f ? x * 12.92f : 1.055f * powf(x, 1.0f / 2.4f) - 0.055f;
+		out[i] = (uint8_t)(e * 255.0f + 0.5f);
+	}
+}
+
+// Everything one GPU does: context, scene, acceleration structure, frames, read-back.
+static int renderOn(Job &j)
+{
+	pt_ctx *ctx = pt_create(j.device);
+	if (!ctx)
+	{
+		fprintf(stderr, "pt_create(%d): %s\n", j.device, pt_last_error(nullptr));
+		return EXIT_FAILURE;
+	}
+	const PtSceneData *sd = j.sd;
+	CHECK(pt_upload_scene(ctx, pt_scene_vertices(sd), pt_scene_n_vertices(sd), pt_scene_indices(sd), pt_scene_n_indices(sd),
+	                      pt_scene_materials(sd), pt_scene_n_materials(sd), pt_scene_mat_indices(sd)));
+	if (!j.texPath.empty())
+	{
+		// diffuse map over Vertex::texCoord (the reference ships textures/viking_room.png but never samples it)
+		uint8_t *texels = nullptr;
+		uint32_t tw = 0, th = 0;
+		CHECK(pt_load_png(j.texPath.c_str(), &texels, &tw, &th));
+		CHECK(pt_set_texture(ctx, texels, tw, th));
+		pt_free(texels);
+	}
+	CHECK(pt_build_accel(ctx, PT_ACCEL_BVH4_PLOC));
+	CHECK(pt_resize(ctx, j.W, j.H));
+	float view[16], proj[16];
+	pt_reference_camera(j.W, j.H, view, proj);
+	CHECK(pt_set_camera(ctx, view, proj));
+	CHECK(pt_set_params(ctx, j.spp, j.depth, 0.001f, 10000.0f, j.seed, j.frames));
+	CHECK(pt_set_frame_schedule(ctx, j.first, j.stride));
+	CHECK(pt_set_accum_mode(ctx, j.accum));
+	if (j.tile[2]) CHECK(pt_set_tile(ctx, j.tile[0], j.tile[1], j.tile[2], j.tile[3]));
+	auto t0 = std::chrono::steady_clock::now();
+	CHECK(pt_render_frames(ctx, j.frames));
+	CHECK(pt_synchronize(ctx));
+	j.seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+	CHECK(pt_get_stats(ctx, &j.stats));
+	j.image.resize(4 * (size_t)j.W * j.H);
+	CHECK(pt_read_image(ctx, j.image.data()));
+	pt_destroy(ctx);
+	return EXIT_SUCCESS;
+}
+
 int main(int argc, char **argv)
 {
 	pt_ctx *ctx = nullptr;
 	if (argc < 2)
 	{
-		fprintf(stderr, "usage: %s scene.obj [-w W] [-h H] [-spp S] [-frames F] [-depth D] [-seed X] [-tex map.png] [-o out.pfm|.ppm|.png]\n", argv[0]);
+		fprintf(stderr, "usage: %s scene.obj [-w W] [-h H] [-spp S] [-frames F] [-depth D] [-seed X] [-tex map.png] [-o out.pfm|.ppm|.png] [-gpus G] [-devices a,b,..] [-split streams|tiles]\n", argv[0]);
 		return EXIT_FAILURE;
 	}
-	std::string objPath = argv[1], out = "out.pfm", texPath;
-	uint32_t W = 800, H = 600, seed = 0;
-	int spp = 10, frames = 100, depth = 20;
+	std::string objPath = argv[1], out = "out.pfm", split = "streams";
+	Job base;
+	int gpus = 1;
+	std::vector<int> devices;
 	for (int i = 2; i + 1 < argc; i += 2)
 	{
 		std::string k = argv[i];
 		const char *v = argv[i + 1];
-		if (k == "-w") W = (uint32_t)atoi(v);
-		else if (k == "-h") H = (uint32_t)atoi(v);
-		else if (k == "-spp") spp = atoi(v);
-		else if (k == "-frames") frames = atoi(v);
-		else if (k == "-depth") depth = atoi(v);
-		else if (k == "-seed") seed = (uint32_t)strtoul(v, nullptr, 0);
+		if (k == "-w") base.W = (uint32_t)atoi(v);
+		else if (k == "-h") base.H = (uint32_t)atoi(v);
+		else if (k == "-spp") base.spp = atoi(v);
+		else if (k == "-frames") base.frames = atoi(v);
+		else if (k == "-depth") base.depth = atoi(v);
+		else if (k == "-seed") base.seed = (uint32_t)strtoul(v, nullptr, 0);
 		else if (k == "-o") out = v;
-		else if (k == "-tex") texPath = v;
+		else if (k == "-tex") base.texPath = v;
+		else if (k == "-gpus") gpus = atoi(v);
+		else if (k == "-split") split = v;
+		else if (k == "-devices")
+		{
+			for (const char *p = v; *p;)
+			{
+				devices.push_back((int)strtol(p, const_cast<char **>(&p), 10));
+				if (*p == ',') ++p;
+				else if (*p) break;
+			}
+		}
 		else
 		{
 			fprintf(stderr, "unknown option %s\n", k.c_str());
 			return EXIT_FAILURE;
 		}
 	}
+	if (gpus < 1 || (split != "streams" && split != "tiles") || (!devices.empty() && (int)devices.size() != gpus) ||
+	    (split == "tiles" && (uint32_t)gpus > base.W) || base.frames < 1)
+	{
+		fprintf(stderr, "bad -gpus / -devices / -split / -frames\n");
+		return EXIT_FAILURE;
+	}
 	PtSceneData *sd = nullptr;
 	CHECK(pt_load_obj(objPath.c_str(), &sd));
 	if (*pt_scene_warnings(sd)) fprintf(stderr, "%s", pt_scene_warnings(sd));
-	ctx = pt_create(0);
-	if (!ctx)
+	base.sd = sd;
+	const uint32_t W = base.W, H = base.H;
+	const bool tiles = split == "tiles";
+	const int perGpu = tiles ? base.frames : (base.frames + gpus - 1) / gpus;
+	const int totalFrames = tiles ? base.frames : perGpu * gpus;
+	std::vector<Job> jobs((size_t)gpus, base);
+	for (int r = 0; r < gpus; ++r)
 	{
-		fprintf(stderr, "pt_create: %s\n", pt_last_error(nullptr));
-		return EXIT_FAILURE;
+		Job &j = jobs[(size_t)r];
+		j.device = devices.empty() ? r : devices[(size_t)r];
+		j.frames = perGpu;
+		if (gpus > 1)
+		{
+			j.accum = PT_ACCUM_SUM;
+			if (tiles)
+			{
+				const uint32_t b = W / (uint32_t)gpus, extra = W % (uint32_t)gpus, ur = (uint32_t)r;
+				j.tile[0] = ur * b + (ur < extra ? ur : extra);
+				j.tile[1] = 0;
+				j.tile[2] = b + (ur < extra ? 1u : 0u);
+				j.tile[3] = H;
+			}
+			else
+			{
+				j.first = (uint32_t)r;
+				j.stride = (uint32_t)gpus;
+			}
+		}
 	}
-	CHECK(pt_upload_scene(ctx, pt_scene_vertices(sd), pt_scene_n_vertices(sd), pt_scene_indices(sd), pt_scene_n_indices(sd),
-	                      pt_scene_materials(sd), pt_scene_n_materials(sd), pt_scene_mat_indices(sd)));
-	if (!texPath.empty())
-	{
-		// diffuse map over Vertex::texCoord (the reference ships textures/viking_room.png but never samples it)
-		uint8_t *texels = nullptr;
-		uint32_t tw = 0, th = 0;
-		CHECK(pt_load_png(texPath.c_str(), &texels, &tw, &th));
-		CHECK(pt_set_texture(ctx, texels, tw, th));
-		pt_free(texels);
-	}
-	CHECK(pt_build_accel(ctx, PT_ACCEL_BVH4_PLOC));
-	CHECK(pt_resize(ctx, W, H));
-	float view[16], proj[16];
-	pt_reference_camera(W, H, view, proj);
-	CHECK(pt_set_camera(ctx, view, proj));
-	CHECK(pt_set_params(ctx, spp, depth, 0.001f, 10000.0f, seed, frames));
 	auto t0 = std::chrono::steady_clock::now();
-	CHECK(pt_render_frames(ctx, frames));
-	CHECK(pt_synchronize(ctx));
-	double sec = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
-	PtStats st;
-	CHECK(pt_get_stats(ctx, &st));
-	printf("%u triangles, BVH4 %u nodes (build %.3f ms); %d frames x %d spp at %ux%u: %.3f s, %.1f Mrays/s, %.2f spp/px/s\n",
-	       st.bvh_tris, st.bvh_nodes, st.build_ms, frames, spp, W, H, sec, st.rays_total / sec / 1e6, frames * spp / sec);
+	if (gpus == 1) jobs[0].rc = renderOn(jobs[0]);
+	else
+	{
+		std::vector<std::thread> th;
+		for (int r = 0; r < gpus; ++r) th.emplace_back([&jobs, r] { jobs[(size_t)r].rc = renderOn(jobs[(size_t)r]); });
+		for (std::thread &t : th) t.join();
+	}
+	const double sec = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+	for (const Job &j : jobs)
+		if (j.rc != EXIT_SUCCESS) return j.rc;
+	std::vector<float> &img = jobs[0].image;
+	double renderSec = jobs[0].seconds;
+	unsigned long long rays = jobs[0].stats.rays_total;
+	if (gpus > 1)
+	{
+		// the reduce(sum) of multigpu.py, in rank order, then the mean over all frames; alpha back to 1 (rgen:92)
+		for (int r = 1; r < gpus; ++r)
+		{
+			const std::vector<float> &o = jobs[(size_t)r].image;
+			for (size_t i = 0; i < img.size(); ++i) img[i] += o[i];
+			if (jobs[(size_t)r].seconds > renderSec) renderSec = jobs[(size_t)r].seconds;
+			rays += jobs[(size_t)r].stats.rays_total;
+		}
+		const float n = (float)totalFrames;
+		for (size_t i = 0; i < img.size(); i += 4)
+		{
+			img[i] /= n;
+			img[i + 1] /= n;
+			img[i + 2] /= n;
+			img[i + 3] = 1.0f;
+		}
+	}
+	const PtStats &st = jobs[0].stats;
+	printf("%u triangles, BVH4 %u nodes (build %.3f ms); %d frames x %d spp at %ux%u on %d GPU%s (%s): %.3f s render (%.3f s with set-up), %.1f Mrays/s, %.2f spp/px/s\n",
+	       st.bvh_tris, st.bvh_nodes, st.build_ms, totalFrames, base.spp, W, H, gpus, gpus > 1 ? "s" : "", gpus > 1 ? split.c_str() : "one context",
+	       renderSec, sec, rays / renderSec / 1e6, totalFrames * base.spp / renderSec);
 	if (st.accel_bytes_uncompacted)  // the reference's log line, VulkanRaytracing.cpp:254-255
 		printf("Reduced size of BLAS by %.1f%% from %llu to %llu\n", 100.0 * (double)(st.accel_bytes_uncompacted - st.accel_bytes) / (double)st.accel_bytes_uncompacted,
 		       (unsigned long long)st.accel_bytes_uncompacted, (unsigned long long)st.accel_bytes);
@@ -96,17 +229,11 @@ int main(int argc, char **argv)
 	if (ext == ".ppm" || ext == ".png")
 	{
 		std::vector<uint8_t> px(4 * (size_t)W * H);
-		CHECK(pt_read_image_srgb8(ctx, px.data()));
+		linearToSrgb8(img.data(), (size_t)W * H, px.data());
 		if (ext == ".png") CHECK(pt_write_png(out.c_str(), px.data(), W, H));
 		else CHECK(pt_write_ppm(out.c_str(), px.data(), W, H));
 	}
-	else
-	{
-		std::vector<float> px(4 * (size_t)W * H);
-		CHECK(pt_read_image(ctx, px.data()));
-		CHECK(pt_write_pfm(out.c_str(), px.data(), W, H));
-	}
+	else CHECK(pt_write_pfm(out.c_str(), img.data(), W, H));
 	pt_scene_free(sd);
-	pt_destroy(ctx);
 	return EXIT_SUCCESS;
 }

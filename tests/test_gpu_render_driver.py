@@ -1,0 +1,103 @@
+"""GPU: the pt_render host driver (C++ over the C ABI; reference: main.cpp's call sequence without the window) and its
+host-thread-per-GPU mode -- `-gpus G` runs one thread and one context per GPU with the sharding rule of
+pathtracer_amd/multigpu.py.  One GPU rehearses the path by naming its ordinal twice (-devices 0,0)."""
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+PT_RENDER = os.path.join(ROOT, "pathtracer_amd", "pt_render")
+
+
+def bits(a):
+    return np.ascontiguousarray(a).view(np.uint32)
+
+
+def read_pfm(path):
+    with open(path, "rb") as f:
+        assert f.readline().strip() == b"PF"
+        w, h = map(int, f.readline().split())
+        scale = float(f.readline())
+        assert scale < 0  # little endian
+        data = np.frombuffer(f.read(), dtype="<f4").reshape(h, w, 3)
+    return data[::-1]  # PFM stores the bottom row first
+
+
+def run(args):
+    r = subprocess.run([PT_RENDER] + args, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout + r.stderr
+    return r.stdout
+
+
+def api_sum(pa, scene, W, H, spp, depth, seed, frames, first=0, stride=1, tile=None):
+    from pathtracer_amd.api import PT_ACCUM_SUM
+    rt = pa.HipRaytracing(0)
+    rt.buildBlas(scene)
+    rt.resize(W, H)
+    view, proj = pa.reference_camera(W, H)
+    rt.setCamera(view, proj)
+    rt.setParams(spp_per_frame=spp, max_depth=depth, seed=seed, max_frames=frames)
+    rt.setFrameSchedule(first=first, stride=stride)
+    rt.setAccumMode(PT_ACCUM_SUM)
+    if tile:
+        rt.setTile(*tile)
+    rt.raytrace(frames)
+    img = rt.readImage()
+    rays = rt.stats().rays_total
+    rt.cleanup()
+    return img, rays
+
+
+def test_pt_render_one_and_two_contexts(pa, tmp_path):
+    """-gpus 1: the image of the API's running mean.  -gpus 2 (sample streams): context r renders global frames r, r+2, ...
+    as raw sums, the host adds them in rank order and divides by the frame count -- bit-identical to the same rule applied
+    through the Python API.  -gpus 3 -split tiles: column strips, identical to ONE context's sum image divided the same way."""
+    from pathtracer_amd import multigpu
+    obj = pa.scenes.write_cornell_box(str(tmp_path))
+    scene = pa.load_obj(obj)
+    W, H, spp, depth, seed, frames = 72, 40, 2, 5, 9, 6
+    common = [obj, "-w", str(W), "-h", str(H), "-spp", str(spp), "-depth", str(depth), "-seed", str(seed), "-frames", str(frames)]
+
+    out1 = str(tmp_path / "one.pfm")
+    log = run(common + ["-o", out1])
+    assert "32 triangles" in log and "Reduced size of BLAS" in log
+    rt = pa.HipRaytracing(0)
+    rt.buildBlas(scene)
+    rt.resize(W, H)
+    rt.setCamera(*pa.reference_camera(W, H))
+    rt.setParams(spp_per_frame=spp, max_depth=depth, seed=seed, max_frames=frames)
+    rt.raytrace(frames)
+    want = rt.readImage()
+    rt.cleanup()
+    assert np.array_equal(bits(read_pfm(out1)), bits(want[..., :3]))
+
+    out2 = str(tmp_path / "two.pfm")
+    log = run(common + ["-gpus", "2", "-devices", "0,0", "-o", out2])
+    assert "on 2 GPUs (streams)" in log
+    acc = None
+    for r in range(2):
+        first, stride = multigpu.frame_schedule(r, 2)
+        img, _ = api_sum(pa, scene, W, H, spp, depth, seed, frames // 2, first, stride)
+        acc = img.copy() if acc is None else acc + img
+    want2 = multigpu.finalize_mean(acc, frames)
+    assert np.array_equal(bits(read_pfm(out2)), bits(want2[..., :3]))
+    assert float(np.abs(want2[..., :3] - want[..., :3]).max()) < 1e-4  # same frames, mean formed in a different order
+
+    out3 = str(tmp_path / "tiles.png")
+    outp = str(tmp_path / "tiles.pfm")
+    run(common + ["-gpus", "3", "-devices", "0,0,0", "-split", "tiles", "-o", outp])
+    whole, _ = api_sum(pa, scene, W, H, spp, depth, seed, frames)
+    want3 = multigpu.finalize_mean(whole.copy(), frames)
+    assert np.array_equal(bits(read_pfm(outp)), bits(want3[..., :3]))
+    run(common + ["-gpus", "3", "-devices", "0,0,0", "-split", "tiles", "-o", out3])
+    assert os.path.getsize(out3) > 100
+
+
+def test_pt_render_rejects_bad_arguments(tmp_path, pa):
+    obj = pa.scenes.write_cornell_box(str(tmp_path))
+    for extra in (["-gpus", "0"], ["-gpus", "2", "-devices", "0"], ["-split", "rows"], ["-gpus", "1", "-devices", "99"]):
+        r = subprocess.run([PT_RENDER, obj, "-w", "16", "-h", "16", "-frames", "1"] + extra, capture_output=True, text=True, timeout=120)
+        assert r.returncode != 0, extra
