@@ -597,6 +597,22 @@ int buildTopLevel(pt_ctx *c, int builder)
 		hipFree(all);
 		return fail(c, PT_EHIP, "pt_build_accel: top-level assembly failed: %s", hipGetErrorString(e));
 	}
+	if (c->quadAccel.nQuads)
+	{
+		// the quad version of the bottom-level nodes gets the same top level behind it
+		PtNode4 *allQ = nullptr;
+		hipError_t qe = hipMalloc(&allQ, sizeof(PtNode4) * ((size_t)c->blasNodes + top.nNodes));
+		if (qe == hipSuccess) qe = hipMemcpy(allQ, c->quadAccel.nodes, sizeof(PtNode4) * c->blasNodes, hipMemcpyDeviceToDevice);
+		if (qe == hipSuccess) qe = hipMemcpy(allQ + c->blasNodes, all + c->blasNodes, sizeof(PtNode4) * top.nNodes, hipMemcpyDeviceToDevice);
+		if (qe != hipSuccess)
+		{
+			hipFree(allQ);
+			hipFree(all);
+			return fail(c, PT_EHIP, "pt_build_accel: top-level assembly failed: %s", hipGetErrorString(qe));
+		}
+		hipFree(c->quadAccel.nodes);
+		c->quadAccel.nodes = allQ;
+	}
 	hipFree(c->accel.nodes);
 	c->accel.nodes = all;
 	c->accel.nNodes = c->blasNodes + top.nNodes;
@@ -662,7 +678,7 @@ extern "C" int pt_build_accel(pt_ctx *c, int flags) try
 			c->accelBytes = fixed + (uint64_t)c->accel.nNodes * sizeof(PtNode4);
 		}
 	}
-	if (!c->nInst && !c->brute && c->accel.nNodes && (leafMax == 0 ? PT_LEAF_DEFAULT : leafMax) <= 7 && !getenv("PT_NO_QUADS"))
+	if (!c->brute && c->accel.nNodes && (leafMax == 0 ? PT_LEAF_DEFAULT : leafMax) <= 7 && !getenv("PT_NO_QUADS"))
 	{
 		// scenes made of quad faces: two-triangle fan leaves become quad leaves for k_paths (pt_build.h)
 		hipError_t qe = ptBuildQuadLeaves(c->accel.nodes, c->accel.nNodes, c->accel.tris, c->accel.nTris, 0.9f, c->quadAccel, c->stream);
@@ -674,19 +690,6 @@ extern "C" int pt_build_accel(pt_ctx *c, int flags) try
 	}
 	// (not for trees of millions of nodes: the children of the entry node are visited in a fixed order, and where a ray
 	// crosses many subtrees the nearest-first descent of the ordinary root is worth more: 20 M-triangle soup 733 vs 672 Mrays/s)
-	if (!c->nInst && !c->brute && c->accel.nNodes && c->accel.nNodes <= (1u << 20) && !(flags & PT_ACCEL_NO_ENTRY_NODE) &&
-	    !getenv("PT_NO_ENTRY"))
-	{
-		// the tree top as one wide node that k_paths tests while it stages a ray (of the node array k_paths traverses)
-		hipError_t ee = ptBuildEntryNode(c->quadAccel.nQuads ? c->quadAccel.nodes : c->accel.nodes, c->accel.nNodes, 0u, c->accel.tris,
-		                                 c->accel.nTris, c->quadAccel.quads, c->quadAccel.nQuads, &c->dEntry, &c->entryFlat, c->stream);
-		if (getenv("PT_NO_FLAT")) c->entryFlat = false;
-		if (ee != hipSuccess)
-		{
-			freeAccel(c);
-			return fail(c, PT_EHIP, "pt_build_accel: entry node failed: %s", hipGetErrorString(ee));
-		}
-	}
 	if (c->nInst && !c->brute && c->accel.nNodes)
 	{
 		int rc = buildTopLevel(c, in.builder);
@@ -694,6 +697,24 @@ extern "C" int pt_build_accel(pt_ctx *c, int flags) try
 		{
 			freeAccel(c);
 			return rc;
+		}
+	}
+	// (two-level scenes: only on request -- a ray crosses many instance boxes there, and visiting the entry node's children
+	// in a fixed order instead of nearest first costs more than the wide first step saves: 64 x 64 grid 5.41 vs 5.78 Grays/s)
+	if (!c->brute && c->accel.nNodes && c->accel.nNodes <= (1u << 20) && !(flags & PT_ACCEL_NO_ENTRY_NODE) && !getenv("PT_NO_ENTRY") &&
+	    (!c->tlasDepth || getenv("PT_ENTRY_TWO_LEVEL")))
+	{
+		// the tree top (two-level scenes: the top of the top-level tree) as one wide node that k_paths tests while it stages
+		// a ray (of the node array k_paths traverses)
+		const bool two = c->tlasDepth != 0;
+		hipError_t ee = ptBuildEntryNode(c->quadAccel.nQuads ? c->quadAccel.nodes : c->accel.nodes, c->accel.nNodes, two ? c->tlasRoot : 0u,
+		                                 c->accel.tris, c->accel.nTris, c->quadAccel.quads, c->quadAccel.nQuads, two, &c->dEntry,
+		                                 &c->entryFlat, c->stream);
+		if (getenv("PT_NO_FLAT")) c->entryFlat = false;
+		if (ee != hipSuccess)
+		{
+			freeAccel(c);
+			return fail(c, PT_EHIP, "pt_build_accel: entry node failed: %s", hipGetErrorString(ee));
 		}
 	}
 	// stack entries a traversal can need: 3 per level (+ the sentinel), per tree (+ the instance marker)
@@ -1033,7 +1054,7 @@ int renderPersistent(pt_ctx *c, int n, bool noAlloc = false)
 		pa.instances = c->dInstances;
 		pa.nInst = c->tlasDepth ? c->nInst : 0;
 		pa.tlasRoot = c->tlasRoot;
-		pa.entry = pa.nInst ? nullptr : c->dEntry;
+		pa.entry = c->dEntry;
 		pa.entryFlat = c->entryFlat ? 1u : 0u;
 		ptLaunchPaths(pa, waves, statsKernel, s);
 		if (e1) hipEventRecord(e1, s);

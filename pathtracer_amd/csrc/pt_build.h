@@ -50,7 +50,8 @@ hipError_t ptBuildQuadLeaves(const PtNode4 *nodes, uint32_t nNodes, const PtTri4
 // Entry node for k_paths (pt_wave_traverse.h): the top of the tree under `root` flattened into one node of up to
 // PT_ENTRY_WIDTH children, as a decoded record of PT_ENTRY_REC 16-byte units in device memory (*rec; nullptr when the tree
 // is empty).  `nodes` is the array k_paths traverses (with quad references when nQuads != 0); leaf children get the exact
-// boxes of their triangles / quads.  *flat: every child is a leaf (the node is the whole scene).  Synchronises the stream.
-// The caller owns the allocation.
+// boxes of their triangles / quads -- unless instanceLeaves: `root` is the root of a top-level tree, whose leaves are
+// instances and keep the tree's boxes.  *flat: every child is a triangle leaf (the node is the whole scene).  Synchronises
+// the stream.  The caller owns the allocation.
 hipError_t ptBuildEntryNode(const PtNode4 *nodes, uint32_t nNodes, uint32_t root, const PtTri48 *tris, uint32_t nTris,
-                            const PtQuad64 *quads, uint32_t nQuads, uint4 **rec, bool *flat, hipStream_t stream);
+                            const PtQuad64 *quads, uint32_t nQuads, bool instanceLeaves, uint4 **rec, bool *flat, hipStream_t stream);

@@ -1338,7 +1338,7 @@ namespace
 // t = fma(plane, 1/d, (origin - o)/d), whose rounding errors are relative to the distance travelled (covered by the test's
 // 1e-6 slack) plus 2^-23 of the node's extent (covered by the padding, 2^-18).
 __global__ void k_entry_node(const PtNode4 *nodes, uint32_t nNodes, uint32_t root, const PtTri48 *plane2, const PtQuad64 *quads2,
-                             float4 *rec)
+                             bool instanceLeaves, float4 *rec)
 {
 	if (threadIdx.x != 0 || blockIdx.x != 0) return;
 	constexpr int W = PT_ENTRY_WIDTH, G = W / 4;
@@ -1420,7 +1420,7 @@ __global__ void k_entry_node(const PtNode4 *nodes, uint32_t nNodes, uint32_t roo
 	float maxAbs = 0.0f;
 	for (int i = 0; i < n; ++i)
 	{
-		if (ref[i] & PT_LEAF_FLAG)
+		if ((ref[i] & PT_LEAF_FLAG) && !instanceLeaves)  // (a top-level leaf is an instance: its box stays the tree's)
 		{
 			// exact box of the leaf's triangles (plane 2 holds the coordinates in x, y, z order)
 			float l3[3] = { INFINITY, INFINITY, INFINITY }, h3[3] = { -INFINITY, -INFINITY, -INFINITY };
@@ -1492,7 +1492,7 @@ __global__ void k_entry_node(const PtNode4 *nodes, uint32_t nNodes, uint32_t roo
 }  // namespace
 
 hipError_t ptBuildEntryNode(const PtNode4 *nodes, uint32_t nNodes, uint32_t root, const PtTri48 *tris, uint32_t nTris,
-                            const PtQuad64 *quads, uint32_t nQuads, uint4 **rec, bool *flat, hipStream_t stream)
+                            const PtQuad64 *quads, uint32_t nQuads, bool instanceLeaves, uint4 **rec, bool *flat, hipStream_t stream)
 {
 	*rec = nullptr;
 	*flat = false;
@@ -1501,7 +1501,7 @@ hipError_t ptBuildEntryNode(const PtNode4 *nodes, uint32_t nNodes, uint32_t root
 	hipError_t e = hipMalloc(&d, sizeof(uint4) * PT_ENTRY_REC);
 	if (e != hipSuccess) return e;
 	k_entry_node<<<1, 64, 0, stream>>>(nodes, nNodes, root, tris + 2 * (size_t)nTris, nQuads ? quads + 2 * (size_t)nQuads : nullptr,
-	                                   reinterpret_cast<float4 *>(d));
+	                                   instanceLeaves, reinterpret_cast<float4 *>(d));
 	e = hipGetLastError();
 	uint32_t head[8] = {};
 	if (e == hipSuccess) e = hipMemcpyAsync(head, d, sizeof(head), hipMemcpyDeviceToHost, stream);
@@ -1512,6 +1512,6 @@ hipError_t ptBuildEntryNode(const PtNode4 *nodes, uint32_t nNodes, uint32_t root
 		return e;
 	}
 	*rec = d;
-	*flat = head[4] != 0u && head[5] == 0u;  // children, inner children
+	*flat = head[4] != 0u && head[5] == 0u && !instanceLeaves;  // children, inner children
 	return hipSuccess;
 }

@@ -63,6 +63,14 @@ constexpr int kDoneRingFull = PT_DONE_RING;  // >= 64 entries; below 127 a retir
 #ifndef PT_DONE_RING_TINY
 #define PT_DONE_RING_TINY 112
 #endif
+#ifndef PT_INST_RING
+#define PT_INST_RING 96
+#endif
+#ifndef PT_INST_STACK
+#define PT_INST_STACK 12
+#endif
+constexpr int kDoneRingInst = PT_INST_RING;  // two-level scenes: their 1.8 KB of saved world rays cost occupancy otherwise
+constexpr int kStackLdsInst = PT_INST_STACK;
 constexpr int kDoneRingTiny = PT_DONE_RING_TINY;             // (only when more than 32 lanes retire at once onto more than 32 parked hits)
 // ring position p + i for p < kDoneRing, i <= kDoneRing (the ring length need not be a power of two)
 template <int kDoneRing>
@@ -161,13 +169,13 @@ template <bool kStats, bool kInst, int kNodeMode, int kEntryMode>
 __global__ void __launch_bounds__(PT_WAVE) PT_PATHS_OCCUPANCY k_paths(PtPathsArgs a)
 {
 	constexpr bool kEntry = kEntryMode != PT_ENTRY_NONE, kFlat = kEntryMode == PT_ENTRY_FLAT;
-	static_assert(!(kEntry && kInst), "the entry node is built for single-level scenes");
+	static_assert(!(kFlat && kInst), "flat: single-level scenes");
 	static_assert(!kFlat || kNodeMode == PT_NODES_GLOBAL, "a flat scene has no nodes to copy");
 	constexpr bool kTiny = kEntry && kNodeMode != PT_NODES_GLOBAL;
-	constexpr int kStackLds = kTiny ? kStackLdsTiny : kStackLdsFull;
-	constexpr int kDoneRing = kTiny ? kDoneRingTiny : kDoneRingFull;
-	constexpr int kInEntry = kInFields;  // entry children the ray hits (kEntry) / first row of the world direction (kInst)
-	constexpr int kInDir = kInFields;
+	constexpr int kStackLds = kInst ? kStackLdsInst : (kTiny ? kStackLdsTiny : kStackLdsFull);
+	constexpr int kDoneRing = kInst ? kDoneRingInst : (kTiny ? kDoneRingTiny : kDoneRingFull);
+	constexpr int kInEntry = kInFields;  // entry children the ray hits (kEntry)
+	constexpr int kInDir = kInFields + (kEntry ? 1 : 0);  // first row of the world direction (kInst)
 	constexpr int kInBest = kInFields + 1;  // kFlat: best hit so far (t, prim, V, W, det) of a ray that was tested while staged
 	__shared__ uint32_t sStack[kFlat ? 1 : kStackLds][PT_WAVE];
 	__shared__ uint32_t sIn[kInFields + (kInst ? 3 : 0) + (kEntry ? 1 : 0) + (kFlat ? 5 : 0)][PT_WAVE];
@@ -760,7 +768,7 @@ __global__ void __launch_bounds__(PT_WAVE) PT_PATHS_OCCUPANCY k_paths(PtPathsArg
 			else
 			{
 				if (kStats && cur != PT_EMPTY_CHILD) ++leafVisits;
-				pt_leaf_step<kStackLds, !kInst>(sc, ray, tmin, best, cur, sp, sStack, lane, mySpill, a.spillStride, triTests,
+				pt_leaf_step<kStackLds, true>(sc, ray, tmin, best, cur, sp, sStack, lane, mySpill, a.spillStride, triTests,
 				                        kInst ? inst : 0u, kInst ? &bestInst : nullptr);
 			}
 		}
@@ -872,16 +880,16 @@ void ptLaunchPaths(const PtPathsArgs &args, uint32_t waves, bool stats, hipStrea
 	const uint32_t nNodes = args.sc.nNodes;
 #define PT_LAUNCH(inst, mode)                                                                        \
 	{                                                                                                \
-		if (args.entry && !(inst))                                                                   \
+		if (args.entry)                                                                              \
 		{                                                                                            \
-			if (stats) k_paths<true, false, mode, PT_ENTRY_TREE><<<waves, PT_WAVE, 0, s>>>(args);    \
-			else k_paths<false, false, mode, PT_ENTRY_TREE><<<waves, PT_WAVE, 0, s>>>(args);         \
+			if (stats) k_paths<true, inst, mode, PT_ENTRY_TREE><<<waves, PT_WAVE, 0, s>>>(args);     \
+			else k_paths<false, inst, mode, PT_ENTRY_TREE><<<waves, PT_WAVE, 0, s>>>(args);          \
 		}                                                                                            \
 		else if (stats) k_paths<true, inst, mode, PT_ENTRY_NONE><<<waves, PT_WAVE, 0, s>>>(args);    \
 		else k_paths<false, inst, mode, PT_ENTRY_NONE><<<waves, PT_WAVE, 0, s>>>(args);              \
 	}
 	if (args.nInst) PT_LAUNCH(true, PT_NODES_GLOBAL)
-	else if (args.entry && args.entryFlat)
+	else if (args.entry && args.entryFlat && !args.nInst)
 	{
 		if (stats) k_paths<true, false, PT_NODES_GLOBAL, PT_ENTRY_FLAT><<<waves, PT_WAVE, 0, s>>>(args);
 		else k_paths<false, false, PT_NODES_GLOBAL, PT_ENTRY_FLAT><<<waves, PT_WAVE, 0, s>>>(args);
