@@ -1,0 +1,113 @@
+"""GPU: the entry node of the persistent pipeline (pt_wave_traverse.h) -- the top of the tree flattened into one 16-wide
+node that is tested while a ray is staged -- in its three forms: none (PT_ACCEL_NO_ENTRY_NODE), tree (the node has inner
+children; PT_NO_FLAT forces it), flat (every child is a leaf: no traversal loop for the first leaf, no stack).  A traversal
+that only culls conservatively returns the brute-force answer, so every form must give the oracle's image and ray count
+bit for bit; the statistics say which form ran."""
+import os
+
+import numpy as np
+import pytest
+
+from conftest import bits
+
+pytestmark = pytest.mark.gpu
+
+
+def _render(rt, pa, scene, view, proj, W, H, flags, env=None, frames=2, spp=3, depth=6, seed=11, profile=True):
+    from pathtracer_amd.api import PT_PROFILE_TRAVERSAL
+    old = {}
+    for k, v in (env or {}).items():
+        old[k] = os.environ.get(k)
+        os.environ[k] = v
+    try:
+        rt.uploadScene(scene)
+        rt.buildBlas(None, flags)
+    finally:
+        for k, v in old.items():
+            if v is None:
+                del os.environ[k]
+            else:
+                os.environ[k] = v
+    rt.resize(W, H)
+    rt.setCamera(view, proj)
+    rt.setParams(spp_per_frame=spp, max_depth=depth, seed=seed)
+    out = {}
+    for prof in ((0, PT_PROFILE_TRAVERSAL) if profile else (0,)):
+        rt.setProfiling(prof)
+        rt.resetFrame()
+        rt.resetStats()
+        rt.raytrace(frames)
+        out[prof] = (rt.readImage(), rt.stats())
+    rt.setProfiling(0)
+    return out
+
+
+@pytest.mark.parametrize("nx,nz,leaf", [(1, 1, 0), (2, 1, 1), (2, 2, 0), (4, 2, 0), (4, 4, 0), (3, 3, 1), (5, 4, 0), (12, 9, 0)])
+def test_entry_node_forms_equal_the_oracle(rt, pa, O, nx, nz, leaf):
+    from pathtracer_amd.api import PT_ACCEL_BVH4, PT_ACCEL_BVH4_PLOC, PT_ACCEL_NO_ENTRY_NODE, PT_PROFILE_TRAVERSAL
+    sc = pa.scenes.grid_mesh(nx, nz, size=2.0, amplitude=0.3)
+    osc = O.OracleScene(sc.vertices, sc.indices, sc.materials, sc.mat_indices)
+    W, H = 80, 56
+    view = pa.look_at((0.1, 1.2, 2.5), (0.0, 0.1, 0.0), (0, 1, 0))
+    proj = pa.perspective(np.radians(45.0), W / H, 0.1, 100.0)
+    proj[5] *= -1
+    want, rays = osc.render(view, proj, W, H, frames=2, spp_per_frame=3, max_depth=6, seed=11)
+    for builder in (PT_ACCEL_BVH4, PT_ACCEL_BVH4_PLOC):
+        base = builder | (leaf << 8)
+        forms = {"default": (base, None), "tree": (base, {"PT_NO_FLAT": "1"}), "none": (base | PT_ACCEL_NO_ENTRY_NODE, None)}
+        visits = {}
+        for name, (flags, env) in forms.items():
+            res = _render(rt, pa, sc, view, proj, W, H, flags, env)
+            for prof, (img, st) in res.items():
+                assert st.rays_total == rays, (name, prof)
+                assert np.array_equal(bits(img), bits(want)), (name, prof, nx, nz)
+            st = res[PT_PROFILE_TRAVERSAL][1]
+            visits[name] = (st.trav_nodes, st.trav_tris, st.trav_hits)
+        assert visits["default"][2] == visits["none"][2] == visits["tree"][2]  # the same hits
+        n_leaves = rt.stats().bvh_tris  # (upper bound on leaves)
+        if nx * nz * 2 <= 16:
+            # at most 16 leaves whatever the builder does: the entry node is the whole scene and a ray visits exactly that node
+            assert visits["default"][0] == rays, (visits, rays)
+        assert visits["tree"][0] <= visits["none"][0]  # the wide first step never adds node visits
+        assert n_leaves == sc.n_tris
+
+
+def test_entry_node_far_from_the_origin(rt, pa, O):
+    """The entry node stores its planes relative to its own origin: a scene (and camera) 10^4 units away from the world
+    origin renders the oracle's image in every form."""
+    from pathtracer_amd.api import PT_ACCEL_BVH4_PLOC, PT_ACCEL_NO_ENTRY_NODE
+    sc0 = pa.scenes.cornell_box()
+    off = np.array([12288.0, -4096.0, 8192.0], np.float32)
+    v = sc0.vertices.copy()
+    v[:, 0:3] += off
+    sc = pa.Scene(v, sc0.indices, sc0.materials, sc0.mat_indices)
+    osc = O.OracleScene(sc.vertices, sc.indices, sc.materials, sc.mat_indices)
+    W, H = 64, 48
+    view = pa.look_at(tuple(off + np.array([0.0, 1.0, 3.4], np.float32)), tuple(off + np.array([0.0, 1.0, 0.0], np.float32)), (0, 1, 0))
+    proj = pa.perspective(np.radians(45.0), W / H, 0.1, 100.0)
+    proj[5] *= -1
+    want, rays = osc.render(view, proj, W, H, frames=2, spp_per_frame=3, max_depth=6, seed=11)
+    assert want[..., :3].max() > 0
+    for flags, env in ((PT_ACCEL_BVH4_PLOC, None), (PT_ACCEL_BVH4_PLOC, {"PT_NO_FLAT": "1"}), (PT_ACCEL_BVH4_PLOC | PT_ACCEL_NO_ENTRY_NODE, None)):
+        res = _render(rt, pa, sc, view, proj, W, H, flags, env, profile=False)
+        img, st = res[0]
+        assert st.rays_total == rays and np.array_equal(bits(img), bits(want)), (flags, env)
+
+
+def test_entry_node_spares_the_wall_a_ray_starts_on(rt, pa, cornell, ocornell):
+    """Cornell box: the entry node carries the exact boxes of its leaves, so the slab of the wall a bounce ray starts on is
+    left before tmin and is not tested; on the 255-step grid of the ordinary nodes it is.  Same image, fewer triangle tests."""
+    from pathtracer_amd.api import PT_ACCEL_BVH4_PLOC, PT_ACCEL_NO_ENTRY_NODE, PT_PROFILE_TRAVERSAL
+    W, H = 160, 120
+    view, proj = pa.reference_camera(W, H)
+    want, rays = ocornell.render(view, proj, W, H, frames=2, spp_per_frame=3, max_depth=6, seed=11)
+    tris = {}
+    for name, flags in (("entry", PT_ACCEL_BVH4_PLOC), ("none", PT_ACCEL_BVH4_PLOC | PT_ACCEL_NO_ENTRY_NODE)):
+        res = _render(rt, pa, cornell, view, proj, W, H, flags)
+        for prof, (img, st) in res.items():
+            assert st.rays_total == rays and np.array_equal(bits(img), bits(want)), (name, prof)
+        st = res[PT_PROFILE_TRAVERSAL][1]
+        tris[name] = st.trav_tris / st.rays_total
+        if name == "entry":
+            assert st.trav_nodes == st.rays_total  # flat: one (wide) node visit per ray, no 4-wide node steps
+    assert tris["entry"] < 0.85 * tris["none"], tris
