@@ -134,12 +134,35 @@ def probe_lavapipe():
             "; no package index to install them; the reference additionally needs a GLFW window surface (main.cpp:239-279)")
 
 
+KERNEL_SOURCES = ("pt_paths.hip", "pt_wave_traverse.h", "pt_device_common.h", "pt_trace.h")
+
+
+def kernel_source_hash():
+    """sha256 over the sources of k_paths (scripts/make_pmc_json.py stamps the same value into the PMC summaries)."""
+    import hashlib
+    h = hashlib.sha256()
+    try:
+        for name in KERNEL_SOURCES:
+            with open(os.path.join(ROOT, "pathtracer_amd", "csrc", name), "rb") as f:
+                h.update(f.read())
+    except OSError:
+        return None
+    return h.hexdigest()[:16]
+
+
 def load_profile_json(name):
+    """A committed PMC summary (profiles/), or None when there is none -- or when it was taken on other kernel sources than
+    the ones in this tree: counter constants of another kernel must not price this one."""
     try:
         with open(os.path.join(ROOT, "profiles", name)) as f:
-            return json.load(f)
+            d = json.load(f)
     except Exception:
         return None
+    if d.get("kernel_sources_sha") and d["kernel_sources_sha"] != kernel_source_hash():
+        sys.stderr.write(f"bench.py: profiles/{name} was taken on other kernel sources ({d.get('commit')}); its counter "
+                         "constants are not used (regenerate: scripts/gpu_round_profile.sh + scripts/collect_profile.sh)\n")
+        return None
+    return d
 
 
 def build_scene(a, pa):

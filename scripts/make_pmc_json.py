@@ -10,12 +10,26 @@ the launch length.
 usage: make_pmc_json.py <gpurun_out/tag> <kernel name as rocprofv3 prints it> <commit>"""
 import csv
 import glob
+import hashlib
 import json
 import os
 import sys
 
 sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 from pmc_summary import load, short
+
+
+KERNEL_SOURCES = ("pt_paths.hip", "pt_wave_traverse.h", "pt_device_common.h", "pt_trace.h")
+
+
+def kernel_source_hash(root):
+    """sha256 over the sources of k_paths: bench.py recomputes it and treats the constants of a profile taken on other
+    sources as stale."""
+    h = hashlib.sha256()
+    for name in KERNEL_SOURCES:
+        with open(os.path.join(root, "pathtracer_amd", "csrc", name), "rb") as f:
+            h.update(f.read())
+    return h.hexdigest()[:16]
 
 
 def line_of(path):
@@ -55,7 +69,8 @@ def main():
     rf, _ = rays_per_launch(line_of(tag_dir + "/pmc_fetch.log"))
     rw, _ = rays_per_launch(line_of(tag_dir + "/pmc_write.log"))
     per_ray = 2.0 * mean(f) * 1024.0 / rf + mean(w) * 1024.0 / rw
-    d = {"kernel": kernel, "commit": commit, "launches_sampled": len(f), "FETCH_SIZE_KiB_mean": mean(f), "WRITE_SIZE_KiB_mean": mean(w),
+    sha = kernel_source_hash(os.path.dirname(prof))
+    d = {"kernel": kernel, "commit": commit, "kernel_sources_sha": sha, "launches_sampled": len(f), "FETCH_SIZE_KiB_mean": mean(f), "WRITE_SIZE_KiB_mean": mean(w),
          "rays_per_launch": rf, "correction": "FETCH_SIZE x2 (gfx950 counts 128-B requests as 64 B), WRITE_SIZE x1",
          "hbm_read_bytes_per_ray": 2.0 * mean(f) * 1024.0 / rf, "hbm_write_bytes_per_ray": mean(w) * 1024.0 / rw,
          "hbm_bytes_per_ray": per_ray, "hbm_bytes_per_launch": per_ray * rf, "command": cmd}
@@ -68,7 +83,7 @@ def main():
     wall = wall_ns(tag_dir + "/pmc_sq2", kernel)
     gui = b.get("GRBM_GUI_ACTIVE")
     clock = mean(gui) / 8.0 / mean(wall) if gui and wall else None  # cycles per ns = GHz
-    v = {"kernel": kernel, "commit": commit, "source": "profiles/%s_pmc_sq.log" % os.path.basename(tag_dir.rstrip("/")),
+    v = {"kernel": kernel, "commit": commit, "kernel_sources_sha": sha, "source": "profiles/%s_pmc_sq.log" % os.path.basename(tag_dir.rstrip("/")),
          "rays_per_launch": ra,
          "valu_wave_insts_per_ray": mean(a["SQ_INSTS_VALU"]) / ra,
          "salu_insts_per_ray": mean(a["SQ_INSTS_SALU"]) / ra,
