@@ -111,3 +111,73 @@ def test_entry_node_spares_the_wall_a_ray_starts_on(rt, pa, cornell, ocornell):
         if name == "entry":
             assert st.trav_nodes == st.rays_total  # flat: one (wide) node visit per ray, no 4-wide node steps
     assert tris["entry"] < 0.85 * tris["none"], tris
+
+
+def _random_scene(pa, seed):
+    """1 .. 48 triangles of mixed kinds: axis-parallel quads (zero-thickness boxes), slivers, degenerate triangles (two equal
+    vertices), duplicates (ties), tiny and room-sized ones; two materials, one emissive."""
+    rng = np.random.default_rng(seed)
+    tris = []
+    n = int(rng.integers(1, 25))
+    for _ in range(n):
+        kind = rng.integers(0, 6)
+        c = rng.uniform(-1.0, 1.0, 3)
+        if kind == 0:  # axis-parallel quad as a fan
+            ax = int(rng.integers(0, 3)); u, v = (ax + 1) % 3, (ax + 2) % 3
+            e = rng.uniform(0.1, 1.5, 2)
+            p = [c.copy() for _ in range(4)]
+            p[1][u] += e[0]; p[2][u] += e[0]; p[2][v] += e[1]; p[3][v] += e[1]
+            tris += [[p[0], p[1], p[2]], [p[0], p[2], p[3]]]
+        elif kind == 1:  # degenerate: two equal vertices
+            a = c + rng.uniform(-0.3, 0.3, 3)
+            tris.append([c, a, a.copy()])
+        elif kind == 2 and tris:  # duplicate of an earlier triangle (equal t: lowest primitive id wins)
+            tris.append([x.copy() for x in tris[int(rng.integers(0, len(tris)))]])
+        elif kind == 3:  # tiny
+            tris.append([c, c + rng.uniform(-1e-3, 1e-3, 3), c + rng.uniform(-1e-3, 1e-3, 3)])
+        elif kind == 4:  # room-sized
+            tris.append([c + rng.uniform(-3, 3, 3) for _ in range(3)])
+        else:
+            tris.append([c + rng.uniform(-0.5, 0.5, 3) for _ in range(3)])
+    t = np.array(tris, dtype=np.float32)
+    nt = t.shape[0]
+    verts = np.zeros((3 * nt, 11), dtype=np.float32)
+    verts[:, 0:3] = t.reshape(-1, 3)
+    nrm = rng.normal(size=(3 * nt, 3)).astype(np.float32)
+    verts[:, 3:6] = nrm / np.linalg.norm(nrm, axis=1, keepdims=True)
+    verts[:, 6:9] = 1.0
+    idx = np.arange(3 * nt, dtype=np.uint32)
+    mats = np.array([[0.8, 0.7, 0.6, 0, 0, 0], [0, 0, 0, 9, 8, 7]], dtype=np.float32)
+    mid = (rng.uniform(size=nt) < 0.25).astype(np.uint32)
+    return pa.Scene(verts, idx, mats, mid)
+
+
+@pytest.mark.parametrize("seed", range(14))
+def test_random_small_scenes_every_form_and_pipeline(rt, pa, O, seed):
+    """Random scenes around the 16-leaf boundary of the flat form, with degenerate and coincident geometry: entry node
+    (flat or tree), PT_NO_FLAT, no entry node, the fused and split pipelines and GPU brute force all give the oracle's image."""
+    from pathtracer_amd.api import (PT_ACCEL_BRUTE_FORCE, PT_ACCEL_BVH4, PT_ACCEL_BVH4_PLOC, PT_ACCEL_NO_ENTRY_NODE,
+                                    PT_PIPELINE_FUSED, PT_PIPELINE_PERSISTENT, PT_PIPELINE_SPLIT)
+    sc = _random_scene(pa, seed)
+    osc = O.OracleScene(sc.vertices, sc.indices, sc.materials, sc.mat_indices)
+    W, H = 48, 36
+    rng = np.random.default_rng(1000 + seed)
+    eye = tuple(rng.uniform(-2.5, 2.5, 3))
+    view = pa.look_at(eye, tuple(rng.uniform(-0.3, 0.3, 3)), (0, 1, 0))
+    proj = pa.perspective(np.radians(60.0), W / H, 0.1, 100.0)
+    proj[5] *= -1
+    want, rays = osc.render(view, proj, W, H, frames=2, spp_per_frame=3, max_depth=6, seed=11)
+    leaf = seed % 3  # default, 1, 2 triangles per leaf
+    cases = [("flat/tree", PT_ACCEL_BVH4_PLOC | (leaf << 8), None, PT_PIPELINE_PERSISTENT),
+             ("tree", PT_ACCEL_BVH4 | (leaf << 8), {"PT_NO_FLAT": "1"}, PT_PIPELINE_PERSISTENT),
+             ("no quads", PT_ACCEL_BVH4_PLOC | (leaf << 8), {"PT_NO_QUADS": "1"}, PT_PIPELINE_PERSISTENT),
+             ("none", PT_ACCEL_BVH4_PLOC | (leaf << 8) | PT_ACCEL_NO_ENTRY_NODE, None, PT_PIPELINE_PERSISTENT),
+             ("fused", PT_ACCEL_BVH4_PLOC | (leaf << 8), None, PT_PIPELINE_FUSED),
+             ("brute", PT_ACCEL_BRUTE_FORCE, None, PT_PIPELINE_SPLIT)]
+    for name, flags, env, pipe in cases:
+        rt.setPipeline(pipe)
+        res = _render(rt, pa, sc, view, proj, W, H, flags, env, profile=False)
+        img, st = res[0]
+        assert st.rays_total == rays, (name, seed)
+        assert np.array_equal(bits(img), bits(want)), (name, seed, sc.n_tris)
+    rt.setPipeline(PT_PIPELINE_PERSISTENT)
