@@ -110,10 +110,13 @@ int pt_synchronize(pt_ctx *ctx);
 
 /* ---- scene + acceleration structure ---------------------------------------------------- */
 
-/* VulkanRaytracing::buildTlas / createInstancesBuffer (VulkanRaytracing.cpp:382-527): the instances of the one
- * bottom-level structure.  transform = VkTransformMatrixKHR (object-to-world, 3x4 row-major); custom_index must
- * be 0 (the reference has one Model, raytrace.rchit:27); mask is kept for layout only (every instance is visible,
- * as with the reference's 0xFF).  n = 0 (default) is the reference's single identity instance and costs nothing.
+/* VulkanRaytracing::buildTlas / createInstancesBuffer (VulkanRaytracing.cpp:382-527): the instances of the
+ * bottom-level structures.  transform = VkTransformMatrixKHR (object-to-world, 3x4 row-major); custom_index selects
+ * the Model the instance shows AND its bottom-level structure (raytrace.rchit:27 model.m[gl_InstanceCustomIndexEXT];
+ * createInstancesBuffer pairs instanceCustomIndex = i with m_blases[i]) -- 0 with pt_upload_scene, < n_models with
+ * pt_upload_models (checked by pt_build_accel); mask is kept for layout only (every instance is visible, as with
+ * the reference's 0xFF).  n = 0 (default) is the reference's own instance list: one identity instance per Model --
+ * for one Model that is a single-level scene and costs nothing.
  * Semantics (Vulkan spec + raytrace.rchit:45-46): the ray is taken into object space with the world-to-object
  * matrix (glm::inverse of the 4x4, fp32 cofactors -- this build's definition of gl_WorldToObjectEXT) WITHOUT
  * renormalising the direction, so hit distances compare across instances; ties go to the lower instance index;
@@ -134,6 +137,25 @@ int pt_set_instances(pt_ctx *ctx, const PtInstance *instances, uint32_t n);
 int pt_upload_scene(pt_ctx *ctx, const PtVertex *vertices, uint32_t n_vertices, const uint32_t *indices,
                     uint32_t n_indices, const PtMaterial *materials, uint32_t n_materials,
                     const uint32_t *mat_indices);
+
+/* Several Models in one scene: the array `model.m[]` of raytrace.rchit:21,27 (struct Model, main.cpp:46-52 /
+ * raycommon.glsl:25; the reference fills in exactly one, main.cpp:1199-1208, and builds one BLAS and one instance,
+ * VulkanRaytracing.cpp:158, 385).  Replaces pt_upload_scene; Model m gets its own bottom-level structure at
+ * pt_build_accel and is shown by every instance whose custom_index is m.  Every model obeys pt_upload_scene's rules
+ * on its own (indices < its n_vertices, mat_indices < its n_materials); gl_PrimitiveID is local to the model as in
+ * Vulkan (PtStats / debug entry points number primitives through all models in order).  n_models >= 1; at most
+ * 2^28-1 triangles in all.  A scene of several models renders on PT_PIPELINE_PERSISTENT. */
+typedef struct PtModelDesc
+{
+	const PtVertex *vertices;
+	uint32_t n_vertices;
+	const uint32_t *indices;
+	uint32_t n_indices;
+	const PtMaterial *materials;
+	uint32_t n_materials;
+	const uint32_t *mat_indices;
+} PtModelDesc;
+int pt_upload_models(pt_ctx *ctx, const PtModelDesc *models, uint32_t n_models);
 
 /* Diffuse map of the scene (BASELINE config 3 "textured").  No counterpart in the reference's
  * shaders: it ships textures/viking_room.png and carries Vertex::texCoord (main.cpp:1166-1176, V flipped) through to

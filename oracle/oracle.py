@@ -17,7 +17,7 @@ class Scene(C.Structure):
     _fields_ = [("verts", C.c_void_p), ("nVerts", C.c_uint32), ("indices", C.c_void_p), ("nIdx", C.c_uint32),
                 ("materials", C.c_void_p), ("nMat", C.c_uint32), ("matIdx", C.c_void_p),
                 ("instances", C.c_void_p), ("nInst", C.c_uint32),
-                ("texture", C.c_void_p), ("texW", C.c_uint32), ("texH", C.c_uint32)]
+                ("texture", C.c_void_p), ("texW", C.c_uint32), ("texH", C.c_uint32), ("instRange", C.c_void_p)]
 
 
 class Params(C.Structure):
@@ -173,7 +173,29 @@ def instance_world_to_object(o2w):
 class OracleScene:
     """Holds the reference-layout buffers (Vertex 44 B, Material 24 B) and an optional BVH."""
 
-    def __init__(self, vertices, indices, materials, mat_indices, use_bvh=None, instances=None, texture=None):
+    @classmethod
+    def from_models(cls, models, instances, custom_index, **kw):
+        """Several Models (each with .vertices .indices .materials .mat_indices) shown by instances: instance i = Model
+        custom_index[i] under transform instances[i].  The buffers are concatenated (indices / material indices rebased),
+        primitive ids run through all models in order -- within one instance that is the order of the local ids."""
+        v0 = m0 = t0 = 0
+        vs, ids, ms, mis, first, count = [], [], [], [], [], []
+        for s in models:
+            vs.append(np.asarray(s.vertices, np.float32).reshape(-1, 11))
+            ids.append(np.asarray(s.indices, np.uint32).reshape(-1) + np.uint32(v0))
+            ms.append(np.asarray(s.materials, np.float32).reshape(-1, 6))
+            mis.append(np.asarray(s.mat_indices, np.uint32).reshape(-1) + np.uint32(m0))
+            first.append(t0)
+            count.append(ids[-1].size // 3)
+            v0 += vs[-1].shape[0]
+            m0 += ms[-1].shape[0]
+            t0 += count[-1]
+        ci = np.asarray(custom_index, np.uint32).reshape(-1)
+        rng = np.stack([np.asarray(first, np.uint32)[ci], np.asarray(count, np.uint32)[ci]], axis=1)
+        return cls(np.concatenate(vs), np.concatenate(ids), np.concatenate(ms), np.concatenate(mis), instances=instances,
+                   inst_range=rng, **kw)
+
+    def __init__(self, vertices, indices, materials, mat_indices, use_bvh=None, instances=None, texture=None, inst_range=None):
         self.vertices = np.ascontiguousarray(vertices, dtype=np.float32).reshape(-1, 11)
         self.indices = np.ascontiguousarray(indices, dtype=np.uint32).reshape(-1)
         self.materials = np.ascontiguousarray(materials, dtype=np.float32).reshape(-1, 6)
@@ -192,6 +214,11 @@ class OracleScene:
                        _p(self.materials), self.materials.shape[0], _p(self.mat_indices),
                        _p(self.instances) if self.instances is not None else None,
                        0 if self.instances is None else self.instances.shape[0])
+        self.inst_range = None
+        if inst_range is not None:
+            self.inst_range = np.ascontiguousarray(inst_range, dtype=np.uint32).reshape(-1, 2)
+            assert self.instances is not None and self.inst_range.shape[0] == self.instances.shape[0]
+            self.c.instRange = self.inst_range.ctypes.data
         # texture: (H, W, 4) uint8 sRGB diffuse map -> linear float texels (IEC 61966-2-1, evaluated in double)
         self.texture = None
         if texture is not None:

@@ -287,6 +287,11 @@ typedef struct
 	 * v 0; NULL = none.  hitValue = material diffuse x pto_sample_texture(interpolated texCoord). */
 	const float *texture;
 	uint32_t texW, texH;
+	/* Several Models (raytrace.rchit:27 model.m[gl_InstanceCustomIndexEXT]; instance i refers to m_blases[i] AND
+	 * Model i, VulkanRaytracing.cpp:395-399): the buffers above hold the models one after the other (indices and material
+	 * indices rebased by the caller), and instance ii contains only the primitives [instRange[2*ii], + instRange[2*ii+1]).
+	 * NULL: every instance shows the whole scene (one Model). */
+	const uint32_t *instRange;
 } PtoScene;
 
 /* Repeat addressing, bilinear filter; every step in fp32 in exactly this order (this build's definition of the
@@ -592,9 +597,11 @@ void pto_intersect_instances(const PtoScene *sc, const PtoBvh *b, const float o[
 		ray_to_object(sc->instances + 24 * (size_t)ii + 12, o, d, oo, od);
 		PtoRayShear rs;
 		ray_shear(od, &rs);
+		const uint32_t pFirst = sc->instRange ? sc->instRange[2 * ii] : 0u;
+		const uint32_t pEnd = sc->instRange ? pFirst + sc->instRange[2 * ii + 1] : nTri;
 		if (!b)
 		{
-			for (uint32_t p = 0; p < nTri; ++p)
+			for (uint32_t p = pFirst; p < pEnd; ++p)
 			{
 				const float *p0 = sc->verts + 11 * (size_t)sc->indices[3 * p + 0];
 				const float *p1 = sc->verts + 11 * (size_t)sc->indices[3 * p + 1];
@@ -615,6 +622,7 @@ void pto_intersect_instances(const PtoScene *sc, const PtoBvh *b, const float o[
 				for (uint32_t i = n->first; i < n->first + n->count; ++i)
 				{
 					uint32_t p = b->prims[i];
+					if (p < pFirst || p >= pEnd) continue; /* a primitive of another Model */
 					const float *p0 = sc->verts + 11 * (size_t)sc->indices[3 * p + 0];
 					const float *p1 = sc->verts + 11 * (size_t)sc->indices[3 * p + 1];
 					const float *p2 = sc->verts + 11 * (size_t)sc->indices[3 * p + 2];

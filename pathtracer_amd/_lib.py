@@ -53,6 +53,7 @@ SYMBOLS = {
     "pt_set_stream": (_i, [_vp, _vp]),
     "pt_synchronize": (_i, [_vp]),
     "pt_upload_scene": (_i, [_vp, _vp, _u32, _vp, _u32, _vp, _u32, _vp]),
+    "pt_upload_models": (_i, [_vp, _vp, _u32]),
     "pt_build_accel": (_i, [_vp, _i]),
     "pt_set_instances": (_i, [_vp, _vp, _u32]),
     "pt_resize": (_i, [_vp, _u32, _u32]),

@@ -226,6 +226,24 @@ class HipRaytracing:
                                             s.indices.size, _p(s.materials), s.materials.shape[0], _p(s.mat_indices)))
         self._scene = s
 
+    def uploadModels(self, scenes):
+        """Several Models in one scene (raytrace.rchit:27 model.m[gl_InstanceCustomIndexEXT]): model m is shown by the
+        instances whose custom_index is m (setInstances), each gets its own bottom-level structure at buildBlas."""
+        import ctypes as C
+
+        class PtModelDesc(C.Structure):
+            _fields_ = [("vertices", C.c_void_p), ("n_vertices", C.c_uint32), ("indices", C.c_void_p), ("n_indices", C.c_uint32),
+                        ("materials", C.c_void_p), ("n_materials", C.c_uint32), ("mat_indices", C.c_void_p)]
+        scenes = list(scenes)
+        arr = (PtModelDesc * max(1, len(scenes)))()
+        for d, s in zip(arr, scenes):
+            d.vertices, d.n_vertices = s.vertices.ctypes.data, s.vertices.shape[0]
+            d.indices, d.n_indices = s.indices.ctypes.data, s.indices.size
+            d.materials, d.n_materials = s.materials.ctypes.data, s.materials.shape[0]
+            d.mat_indices = s.mat_indices.ctypes.data
+        self._check(self._L.pt_upload_models(self._ctx, C.cast(arr, C.c_void_p) if scenes else None, len(scenes)))
+        self._scene = scenes[0] if len(scenes) == 1 else None
+
     def buildBlas(self, scene: Scene | None = None, flags: int = PT_ACCEL_BVH4_PLOC):
         """VulkanRaytracing::buildBlas (VulkanRaytracing.cpp:147-262): here the BVH is built by our own
         kernels instead of the driver.  Includes buildTlas (single identity instance)."""
@@ -233,9 +251,10 @@ class HipRaytracing:
             self.uploadScene(scene)
         self._check(self._L.pt_build_accel(self._ctx, int(flags)))
 
-    def setInstances(self, transforms=None):
+    def setInstances(self, transforms=None, custom_index=None):
         """createInstancesBuffer (VulkanRaytracing.cpp:382-411): `transforms` = (n, 12) object-to-world 3x4
-        row-major matrices, or None/empty for the reference's single identity instance.  Call before buildBlas."""
+        row-major matrices, or None/empty for the reference's own list (one identity instance per Model);
+        custom_index = the Model of every instance (default 0).  Call before buildBlas."""
         if transforms is None or len(transforms) == 0:
             self._check(self._L.pt_set_instances(self._ctx, None, 0))
             return
@@ -243,6 +262,8 @@ class HipRaytracing:
         rec = np.zeros(t.shape[0], dtype=INSTANCE_DTYPE)
         rec["transform"] = t
         rec["mask"] = 0xFF
+        if custom_index is not None:
+            rec["custom_index"] = np.asarray(custom_index, dtype=np.uint32).reshape(-1)
         self._check(self._L.pt_set_instances(self._ctx, _p(rec), t.shape[0]))
 
     def setTexture(self, rgba8=None):

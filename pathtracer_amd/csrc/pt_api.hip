@@ -80,6 +80,12 @@ struct pt_ctx
 	std::vector<float> instances;
 	float *dInstances = nullptr;
 	uint32_t nInst = 0, tlasRoot = 0, blasNodes = 0, tlasDepth = 0;
+	// several Models (pt_upload_models): the buffers above hold them one after the other; model m owns the triangles
+	// [modelTriFirst[m], + modelTriCount[m]) and, after pt_build_accel, the bottom-level tree rooted at node modelRoot[m]
+	std::vector<uint32_t> modelTriFirst{ 0u }, modelTriCount{ 0u }, modelRoot{ 0u };
+	std::vector<uint32_t> instModel;  // custom_index of every instance
+	bool implicitInst = false;        // the instance list is pt_build_accel's own (one identity instance per Model)
+	uint32_t *dInstRoot = nullptr;    // per instance: root node of its model's tree
 
 	// frame state
 	uint32_t W = 0, H = 0;
@@ -158,6 +164,8 @@ void freeAccel(pt_ctx *c)
 {
 	hipFree(c->dInstances);
 	c->dInstances = nullptr;
+	hipFree(c->dInstRoot);
+	c->dInstRoot = nullptr;
 	c->tlasRoot = c->blasNodes = c->tlasDepth = 0;
 	hipFree(c->accel.nodes);
 	hipFree(c->accel.tris);
@@ -478,6 +486,15 @@ extern "C" int pt_upload_scene(pt_ctx *c, const PtVertex *v, uint32_t nV, const 
 		PT_HIP(c, hipMemcpy(c->dPrimEmissive, emissive.data(), nTris, hipMemcpyHostToDevice));
 	}
 	c->haveScene = true;
+	c->modelTriFirst.assign(1, 0u);
+	c->modelTriCount.assign(1, nTris);
+	if (c->implicitInst)
+	{
+		c->instances.clear();
+		c->instModel.clear();
+		c->nInst = 0;
+		c->implicitInst = false;
+	}
 	if (nTris && !getenv("PT_NO_SHADE_RECORDS"))
 	{
 		PT_HIP(c, hipMalloc(&c->dShade, sizeof(PtShadeRec) * (size_t)nTris));
@@ -491,6 +508,65 @@ extern "C" int pt_upload_scene(pt_ctx *c, const PtVertex *v, uint32_t nV, const 
 catch (const std::bad_alloc &)
 {
 	return fail(c, PT_ENOMEM, "pt_upload_scene: out of host memory");
+}
+
+extern "C" int pt_upload_models(pt_ctx *c, const PtModelDesc *models, uint32_t nModels) try
+{
+	if (!c) return fail(nullptr, PT_EINVAL, "null context");
+	if (!models || !nModels) return fail(c, PT_EINVAL, "pt_upload_models: no models");
+	if (nModels == 1)
+		return pt_upload_scene(c, models[0].vertices, models[0].n_vertices, models[0].indices, models[0].n_indices, models[0].materials,
+		                       models[0].n_materials, models[0].mat_indices);
+	// One set of buffers: vertices, materials and triangles of the models one after the other, indices and material indices
+	// rebased -- so a primitive id that runs through all models reaches the right vertices and material without any per-model
+	// address table on the device (what raytrace.rchit:27-37 does through Model's four buffer addresses).
+	uint64_t nV = 0, nIdx = 0, nM = 0;
+	for (uint32_t m = 0; m < nModels; ++m)
+	{
+		const PtModelDesc &d = models[m];
+		if (d.n_indices % 3) return fail(c, PT_EINVAL, "pt_upload_models: model %u: n_indices (%u) is not a multiple of 3", m, d.n_indices);
+		if (!d.n_indices || !d.vertices || !d.indices || !d.materials || !d.mat_indices || !d.n_vertices || !d.n_materials)
+			return fail(c, PT_EINVAL, "pt_upload_models: model %u: null/empty buffer", m);
+		for (uint32_t i = 0; i < d.n_indices; ++i)
+			if (d.indices[i] >= d.n_vertices)
+				return fail(c, PT_EINVAL, "pt_upload_models: model %u: index %u = %u out of range (%u vertices)", m, i, d.indices[i], d.n_vertices);
+		for (uint32_t t = 0; t < d.n_indices / 3; ++t)
+			if (d.mat_indices[t] >= d.n_materials)
+				return fail(c, PT_EINVAL, "pt_upload_models: model %u: mat_indices[%u] = %u out of range (%u materials)", m, t, d.mat_indices[t],
+				            d.n_materials);
+		nV += d.n_vertices;
+		nIdx += d.n_indices;
+		nM += d.n_materials;
+	}
+	if (nIdx / 3 > 0x0FFFFFFFull || nV > 0xFFFFFFF0ull || nM > 0xFFFFFFF0ull)
+		return fail(c, PT_ELIMIT, "pt_upload_models: more than 2^28-1 triangles (or 2^32 vertices / materials) in all");
+	std::vector<PtVertex> v((size_t)nV);
+	std::vector<uint32_t> idx((size_t)nIdx), mid((size_t)(nIdx / 3));
+	std::vector<PtMaterial> mat((size_t)nM);
+	std::vector<uint32_t> first(nModels), count(nModels);
+	size_t v0 = 0, i0 = 0, m0 = 0;
+	for (uint32_t m = 0; m < nModels; ++m)
+	{
+		const PtModelDesc &d = models[m];
+		memcpy(v.data() + v0, d.vertices, sizeof(PtVertex) * d.n_vertices);
+		memcpy(mat.data() + m0, d.materials, sizeof(PtMaterial) * d.n_materials);
+		for (uint32_t i = 0; i < d.n_indices; ++i) idx[i0 + i] = d.indices[i] + (uint32_t)v0;
+		for (uint32_t t = 0; t < d.n_indices / 3; ++t) mid[i0 / 3 + t] = d.mat_indices[t] + (uint32_t)m0;
+		first[m] = (uint32_t)(i0 / 3);
+		count[m] = d.n_indices / 3;
+		v0 += d.n_vertices;
+		i0 += d.n_indices;
+		m0 += d.n_materials;
+	}
+	int rc = pt_upload_scene(c, v.data(), (uint32_t)nV, idx.data(), (uint32_t)nIdx, mat.data(), (uint32_t)nM, mid.data());
+	if (rc) return rc;
+	c->modelTriFirst.swap(first);
+	c->modelTriCount.swap(count);
+	return PT_OK;
+}
+catch (const std::bad_alloc &)
+{
+	return fail(c, PT_ENOMEM, "pt_upload_models: out of host memory");
 }
 
 extern "C" int pt_set_texture(pt_ctx *c, const uint8_t *rgba8, uint32_t w, uint32_t h) try
@@ -532,26 +608,35 @@ namespace
 // placed behind the bottom-level nodes in one array so that node references are global.
 int buildTopLevel(pt_ctx *c, int builder)
 {
-	PtNode4 root;
-	PT_HIP(c, hipMemcpy(&root, c->accel.nodes, sizeof(root), hipMemcpyDeviceToHost));
-	float lo[3] = { INFINITY, INFINITY, INFINITY }, hi[3] = { -INFINITY, -INFINITY, -INFINITY };
-	const float scale[3] = { root.scaleX, root.scaleY, root.scaleZ };
-	for (int ch = 0; ch < 4; ++ch)
+	// object-space box of every Model = the box of its tree's root node
+	const size_t nModels = c->modelRoot.size();
+	std::vector<float> mlo(3 * nModels, INFINITY), mhi(3 * nModels, -INFINITY);
+	for (size_t m = 0; m < nModels; ++m)
 	{
-		if (root.child[ch] == PT_EMPTY_CHILD) continue;
-		for (int a = 0; a < 3; ++a)
+		PtNode4 root;
+		PT_HIP(c, hipMemcpy(&root, c->accel.nodes + c->modelRoot[m], sizeof(root), hipMemcpyDeviceToHost));
+		const float scale[3] = { root.scaleX, root.scaleY, root.scaleZ };
+		for (int ch = 0; ch < 4; ++ch)
 		{
-			float l = fmaf((float)((root.qlo[a] >> (8 * ch)) & 0xFFu), scale[a], root.origin[a]);
-			float h = fmaf((float)((root.qhi[a] >> (8 * ch)) & 0xFFu), scale[a], root.origin[a]);
-			lo[a] = fminf(lo[a], l);
-			hi[a] = fmaxf(hi[a], h);
+			if (root.child[ch] == PT_EMPTY_CHILD) continue;
+			for (int a = 0; a < 3; ++a)
+			{
+				float l = fmaf((float)((root.qlo[a] >> (8 * ch)) & 0xFFu), scale[a], root.origin[a]);
+				float h = fmaf((float)((root.qhi[a] >> (8 * ch)) & 0xFFu), scale[a], root.origin[a]);
+				mlo[3 * m + a] = fminf(mlo[3 * m + a], l);
+				mhi[3 * m + a] = fmaxf(mhi[3 * m + a], h);
+			}
 		}
 	}
 	const uint32_t n = c->nInst;
 	std::vector<float4> bl(n), bh(n);
+	std::vector<uint32_t> roots(n);
 	for (uint32_t i = 0; i < n; ++i)
 	{
 		const float *t = &c->instances[(size_t)i * 24];
+		const uint32_t model = c->instModel[i];
+		const float *lo = &mlo[3 * (size_t)model], *hi = &mhi[3 * (size_t)model];
+		roots[i] = c->modelRoot[model];
 		float wl[3] = { INFINITY, INFINITY, INFINITY }, wh[3] = { -INFINITY, -INFINITY, -INFINITY };
 		for (int corner = 0; corner < 8; ++corner)
 		{
@@ -588,6 +673,8 @@ int buildTopLevel(pt_ctx *c, int builder)
 	if (e == hipSuccess) e = hipMalloc(&c->dInstances, sizeof(float) * c->instances.size());
 	if (e == hipSuccess)
 		e = hipMemcpy(c->dInstances, c->instances.data(), sizeof(float) * c->instances.size(), hipMemcpyHostToDevice);
+	if (e == hipSuccess) e = hipMalloc(&c->dInstRoot, sizeof(uint32_t) * roots.size());
+	if (e == hipSuccess) e = hipMemcpy(c->dInstRoot, roots.data(), sizeof(uint32_t) * roots.size(), hipMemcpyHostToDevice);
 	hipFree(top.nodes);
 	hipFree(top.tris);
 	hipFree(top.codes);
@@ -634,6 +721,30 @@ extern "C" int pt_build_accel(pt_ctx *c, int flags) try
 	PT_HIP(c, hipStreamSynchronize(c->stream));
 	freeAccel(c);
 	c->brute = (mode == PT_ACCEL_BRUTE_FORCE);
+	const uint32_t nModels = (uint32_t)c->modelTriCount.size();
+	if (nModels > 1)
+	{
+		if (c->brute) return fail(c, PT_EINVAL, "pt_build_accel: PT_ACCEL_BRUTE_FORCE traces one Model");
+		if (c->nInst == 0 || c->implicitInst)
+		{
+			// the reference's own instance list (createInstancesBuffer, VulkanRaytracing.cpp:382-411): instance i = Model i,
+			// identity transform
+			c->instances.assign((size_t)nModels * 24, 0.0f);
+			c->instModel.resize(nModels);
+			for (uint32_t m = 0; m < nModels; ++m)
+			{
+				float *t = &c->instances[(size_t)m * 24];
+				t[0] = t[5] = t[10] = t[12] = t[17] = t[22] = 1.0f;
+				c->instModel[m] = m;
+			}
+			c->nInst = nModels;
+			c->implicitInst = true;
+		}
+	}
+	for (uint32_t i = 0; i < c->nInst; ++i)
+		if (c->instModel[i] >= nModels)
+			return fail(c, PT_EINVAL, "pt_build_accel: instance %u: custom_index %u, but the scene has %u Model%s", i, c->instModel[i], nModels,
+			            nModels == 1 ? "" : "s");
 	// The Morton codes / sorted order / BVH are built in both modes (the debug entry points read
 	// them); brute-force mode just does not traverse the hierarchy.
 	PtBuildInput in = { c->dVerts, c->dIndices, c->nIdx / 3, leafMax,
@@ -641,7 +752,67 @@ extern "C" int pt_build_accel(pt_ctx *c, int flags) try
 	hipEvent_t a = getEvent(c), b = getEvent(c);
 	const bool timed = a && b;  // without events the build is simply not timed
 	if (timed) hipEventRecord(a, c->stream);
-	hipError_t e = ptBuildBvh4(in, c->accel, c->stream);
+	hipError_t e = hipSuccess;
+	c->modelRoot.assign(nModels, 0u);
+	if (nModels == 1) e = ptBuildBvh4(in, c->accel, c->stream);
+	else
+	{
+		// one bottom-level tree per Model (buildBlas loops over blasInputs, VulkanRaytracing.cpp:158-262), each built over its
+		// own slice of the index buffer, then moved into ONE node array and ONE triangle array so that node and leaf
+		// references are global and the traversal needs nothing per model but its root
+		std::vector<PtBuildOutput> parts(nModels);
+		uint64_t nodes = 0;
+		for (uint32_t m = 0; m < nModels && e == hipSuccess; ++m)
+		{
+			PtBuildInput im = in;
+			im.indices = c->dIndices + 3 * (size_t)c->modelTriFirst[m];
+			im.nTris = c->modelTriCount[m];
+			e = ptBuildBvh4(im, parts[m], c->stream);
+			if (e == hipSuccess && parts[m].nNodes == 0) e = hipErrorInvalidValue;
+			nodes += parts[m].nNodes;
+		}
+		PtBuildOutput all;
+		const uint32_t total = c->nIdx / 3;
+		if (e == hipSuccess && nodes > 0x7FFFFFF0ull) e = hipErrorInvalidValue;
+		if (e == hipSuccess) e = hipMalloc(&all.nodes, sizeof(PtNode4) * (size_t)nodes);
+		if (e == hipSuccess) e = hipMalloc(&all.tris, sizeof(PtTri48) * 3 * (size_t)total);
+		if (e == hipSuccess) e = hipMalloc(&all.codes, 4 * (size_t)total);
+		if (e == hipSuccess) e = hipMalloc(&all.order, 4 * (size_t)total);
+		uint32_t nodeBase = 0;
+		for (uint32_t m = 0; m < nModels && e == hipSuccess; ++m)
+		{
+			c->modelRoot[m] = nodeBase;
+			e = ptRelocateBlas(parts[m], nodeBase, c->modelTriFirst[m], total, all.nodes, all.tris, all.codes, all.order, c->stream);
+			nodeBase += parts[m].nNodes;
+			if (parts[m].depth > all.depth) all.depth = parts[m].depth;
+			for (int k = 0; k < 3; ++k)
+			{
+				all.cmin[k] = m ? fminf(all.cmin[k], parts[m].cmin[k]) : parts[m].cmin[k];
+				all.cmax[k] = m ? fmaxf(all.cmax[k], parts[m].cmax[k]) : parts[m].cmax[k];
+			}
+		}
+		if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+		for (PtBuildOutput &p : parts)
+		{
+			hipFree(p.nodes);
+			hipFree(p.tris);
+			hipFree(p.codes);
+			hipFree(p.order);
+		}
+		if (e == hipSuccess)
+		{
+			all.nNodes = nodeBase;
+			all.nTris = total;
+			c->accel = all;
+		}
+		else
+		{
+			hipFree(all.nodes);
+			hipFree(all.tris);
+			hipFree(all.codes);
+			hipFree(all.order);
+		}
+	}
 	float ms = 0.0f;
 	if (timed)
 	{
@@ -662,7 +833,8 @@ extern "C" int pt_build_accel(pt_ctx *c, int flags) try
 		const uint64_t fixed = nPrims * (3 * sizeof(PtTri48) + 8);  // leaf triangles (three planes) + codes + order
 		c->accelBytesUncompacted = fixed + nPrims * sizeof(PtNode4);
 		c->accelBytes = c->accelBytesUncompacted;
-		if (compact && c->accel.nNodes && c->accel.nNodes < nPrims)
+		if (nModels > 1) c->accelBytes = fixed + (uint64_t)c->accel.nNodes * sizeof(PtNode4);  // assembled at its exact size
+		else if (compact && c->accel.nNodes && c->accel.nNodes < nPrims)
 		{
 			PtNode4 *exact = nullptr;
 			hipError_t ce = hipMalloc(&exact, sizeof(PtNode4) * (size_t)c->accel.nNodes);
@@ -740,11 +912,10 @@ extern "C" int pt_set_instances(pt_ctx *c, const PtInstance *inst, uint32_t n) t
 	if (n && !inst) return fail(c, PT_EINVAL, "pt_set_instances: null array");
 	if (n > 0x0FFFFFF0u) return fail(c, PT_ELIMIT, "pt_set_instances: too many instances");
 	std::vector<float> v((size_t)n * 24);
+	std::vector<uint32_t> model(n);
 	for (uint32_t i = 0; i < n; ++i)
 	{
-		if (inst[i].custom_index != 0)
-			return fail(c, PT_EINVAL, "pt_set_instances: instance %u: custom_index %u (one Model only, as in the reference)", i,
-			            inst[i].custom_index);
+		model[i] = inst[i].custom_index;  // checked against the number of Models by pt_build_accel
 		const float *t = inst[i].transform;
 		for (int k = 0; k < 12; ++k)
 			if (!(fabsf(t[k]) <= 3.0e38f)) return fail(c, PT_EINVAL, "pt_set_instances: instance %u: non-finite transform", i);
@@ -767,6 +938,8 @@ extern "C" int pt_set_instances(pt_ctx *c, const PtInstance *inst, uint32_t n) t
 			}
 	}
 	c->instances.swap(v);
+	c->instModel.swap(model);
+	c->implicitInst = false;
 	c->nInst = n;
 	c->haveAccel = false;  // the top-level structure must be rebuilt: pt_build_accel
 	c->frame = -1;
@@ -1054,6 +1227,7 @@ int renderPersistent(pt_ctx *c, int n, bool noAlloc = false)
 		pa.instances = c->dInstances;
 		pa.nInst = c->tlasDepth ? c->nInst : 0;
 		pa.tlasRoot = c->tlasRoot;
+		pa.instRoot = c->dInstRoot;
 		pa.entry = c->dEntry;
 		pa.entryFlat = c->entryFlat ? 1u : 0u;
 		ptLaunchPaths(pa, waves, statsKernel, s);

@@ -55,3 +55,10 @@ hipError_t ptBuildQuadLeaves(const PtNode4 *nodes, uint32_t nNodes, const PtTri4
 // the stream.  The caller owns the allocation.
 hipError_t ptBuildEntryNode(const PtNode4 *nodes, uint32_t nNodes, uint32_t root, const PtTri48 *tris, uint32_t nTris,
                             const PtQuad64 *quads, uint32_t nQuads, bool instanceLeaves, uint4 **rec, bool *flat, hipStream_t stream);
+
+// Several Models in one scene: copies the tree `part` (built over the triangles [triBase, triBase + part.nTris) of the
+// concatenated scene, with local primitive ids) into the shared arrays -- nodes at nodeBase (inner references + nodeBase, leaf
+// references + triBase), triangle records at triBase of every plane of `tris` (plane pitch totalTris; primitive ids + triBase),
+// codes and sorted order likewise.  Asynchronous on `stream`.
+hipError_t ptRelocateBlas(const PtBuildOutput &part, uint32_t nodeBase, uint32_t triBase, uint32_t totalTris, PtNode4 *nodes,
+                          PtTri48 *tris, uint32_t *codes, uint32_t *order, hipStream_t stream);

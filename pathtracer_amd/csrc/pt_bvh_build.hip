@@ -1515,3 +1515,52 @@ hipError_t ptBuildEntryNode(const PtNode4 *nodes, uint32_t nNodes, uint32_t root
 	*flat = head[4] != 0u && head[5] == 0u && !instanceLeaves;  // children, inner children
 	return hipSuccess;
 }
+
+// ------------------------------------------------------------- several bottom-level trees in one set of arrays ----
+namespace
+{
+__global__ void __launch_bounds__(kBlock) k_relocate_nodes(const PtNode4 *src, uint32_t n, uint32_t nodeBase, uint32_t triBase, PtNode4 *dst)
+{
+	const uint32_t i = blockIdx.x * kBlock + threadIdx.x;
+	if (i >= n) return;
+	PtNode4 nd = src[i];
+#pragma unroll
+	for (int c = 0; c < 4; ++c)
+	{
+		const uint32_t r = nd.child[c];
+		if (r == PT_EMPTY_CHILD) continue;
+		nd.child[c] = (r & PT_LEAF_FLAG) ? ((r & 0xF0000000u) | ((r & 0x0FFFFFFFu) + triBase)) : r + nodeBase;
+	}
+	dst[nodeBase + i] = nd;
+}
+
+__global__ void __launch_bounds__(kBlock)
+    k_relocate_tris(const PtTri48 *src, uint32_t n, uint32_t triBase, uint32_t total, PtTri48 *dst)
+{
+	const uint32_t i = blockIdx.x * kBlock + threadIdx.x;
+	if (i >= 3u * n) return;
+	const uint32_t plane = i / n, j = i - plane * n;
+	PtTri48 t = src[i];
+	t.prim += triBase;  // primitive ids run through all models in order
+	dst[(size_t)plane * total + triBase + j] = t;
+}
+
+__global__ void __launch_bounds__(kBlock) k_relocate_u32(const uint32_t *src, uint32_t n, uint32_t add, uint32_t *dst)
+{
+	const uint32_t i = blockIdx.x * kBlock + threadIdx.x;
+	if (i < n) dst[i] = src[i] + add;
+}
+}  // namespace
+
+hipError_t ptRelocateBlas(const PtBuildOutput &part, uint32_t nodeBase, uint32_t triBase, uint32_t totalTris, PtNode4 *nodes,
+                          PtTri48 *tris, uint32_t *codes, uint32_t *order, hipStream_t stream)
+{
+	if (part.nNodes) k_relocate_nodes<<<divUp(part.nNodes, kBlock), kBlock, 0, stream>>>(part.nodes, part.nNodes, nodeBase, triBase, nodes);
+	if (part.nTris)
+	{
+		k_relocate_tris<<<divUp(3u * part.nTris, kBlock), kBlock, 0, stream>>>(part.tris, part.nTris, triBase, totalTris, tris);
+		k_relocate_u32<<<divUp(part.nTris, kBlock), kBlock, 0, stream>>>(part.codes, part.nTris, 0u, codes + triBase);
+		k_relocate_u32<<<divUp(part.nTris, kBlock), kBlock, 0, stream>>>(part.order, part.nTris, triBase, order + triBase);
+	}
+	return hipGetLastError();
+}

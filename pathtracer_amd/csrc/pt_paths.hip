@@ -761,7 +761,7 @@ __global__ void __launch_bounds__(PT_WAVE) PT_PATHS_OCCUPANCY k_paths(PtPathsArg
 					Sz = pr.Sz;
 					kpack = pr.kpack | (kpack & 0xFFFF0000u);  // keep the depth bits
 					pt_stack_push<kStackLds>(PT_INSTANCE_END, sp, sStack, lane, mySpill, a.spillStride);
-					cur = 0u;  // bottom-level root
+					cur = a.instRoot[inst];  // root of the bottom-level tree of the instance's Model
 					if (kStats) ++leafVisits;
 				}
 			}

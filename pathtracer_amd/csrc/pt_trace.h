@@ -90,6 +90,7 @@ struct PtPathsArgs
 	// sc.nodes holds the bottom-level tree at index 0 and the top-level tree at tlasRoot; nInst == 0: single level
 	const float *instances;
 	uint32_t nInst, tlasRoot;
+	const uint32_t *instRoot;  // per instance: root node of the bottom-level tree of its Model (pt_upload_models)
 	const uint4 *entry;  // entry node (PT_ENTRY_REC 16-byte units, pt_wave_traverse.h) or nullptr: every ray starts at the root
 	uint32_t entryFlat;  // every child of the entry node is a leaf: the whole scene is that one node
 };
