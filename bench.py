@@ -266,7 +266,10 @@ def main():
         # scene like the Cornell box also its first leaf test -- happens in the staging phase, with all 64 lanes
         divergence = {"node_step_lane_util": (round(ts.trav_nodes / (64.0 * ts.trav_node_steps), 4)
                                               if ts.trav_node_steps else None),
-                      "leaf_step_lane_util": round(ts.trav_leaf_visits / (64.0 * ts.trav_leaf_steps), 4),
+                      # (flat scenes: trav_leaf_visits includes the first leaf of every ray, tested while staging -- the ratio
+                      # says nothing about the loop then)
+                      "leaf_step_lane_util": (round(ts.trav_leaf_visits / (64.0 * ts.trav_leaf_steps), 4)
+                                              if ts.trav_leaf_visits <= 64.0 * ts.trav_leaf_steps else None),
                       "node_steps_per_64_rays": round(64.0 * ts.trav_node_steps / rays_stat, 3),
                       "leaf_steps_per_64_rays": round(64.0 * ts.trav_leaf_steps / rays_stat, 3),
                       "leaf_visits_per_ray": round(ts.trav_leaf_visits / rays_stat, 3)}
