@@ -561,15 +561,30 @@ __global__ void __launch_bounds__(kBlock) k_refit(const float4 *triPos, const fl
 		hi[0] = h4.x + pad; hi[1] = h4.y + pad; hi[2] = h4.z + pad;
 	}
 	bool local = true;
+	bool skipStore = false;
+	{
+		// A triangle leaf whose parent lies inside this block hands its box over in LDS, and the collapse recomputes the box
+		// of a single-triangle leaf child from the triangle record (k_collapse_level): no 32-byte store for 99 % of the leaves.
+		if (triPos && p >= 0)
+		{
+			const int j = reinterpret_cast<const int *>(topo + p)[3];
+			const int first = j < p ? j : p, last = j < p ? p : j;
+			skipStore = first >= base && last < base + kBlock;
+		}
+	}
 	for (;;)
 	{
 		// Every lane that arrives, first or second, stores the node's box here: consecutive lanes write consecutive 32-byte
 		// boxes, whole lines at a time.  (Measured at 100 M triangles, this kernel 12.8 ms: the same stores split between the
 		// two arrivals 31 ms; the record requested a level ahead and LDS-only fences, so that no wait covers a store, 22 ms --
 		// the full waits pace the stores, and the memory system does better paced.)
-		float4 *dst = reinterpret_cast<float4 *>(boxes + 8 * (size_t)cur);
-		dst[0] = make_float4(lo[0], lo[1], lo[2], 0.0f);
-		dst[1] = make_float4(hi[0], hi[1], hi[2], 0.0f);
+		if (!skipStore)
+		{
+			float4 *dst = reinterpret_cast<float4 *>(boxes + 8 * (size_t)cur);
+			dst[0] = make_float4(lo[0], lo[1], lo[2], 0.0f);
+			dst[1] = make_float4(hi[0], hi[1], hi[2], 0.0f);
+		}
+		skipStore = false;
 		if (p < 0) return;  // cur is the root
 		const int4 t = topo[p];  // children, parent of p, other end of p's range: one load per level
 		if (local)
@@ -642,8 +657,9 @@ constexpr int kMaxLevels = 32;  // trees deeper than the traversal stack allows 
 __global__ void __launch_bounds__(kBlock)
     k_collapse_level(const CollapseTask *tasksIn, CollapseTask *tasksOut, uint32_t *levelCount, int level, Bvh2View bvh,
                      const float *boxes, const uint32_t *sortedPrim, bool boxMode, uint32_t *leafPrim, PtNode4 *nodes,
-                     uint32_t *triCount, int leafMax, uint32_t nodeBase)
+                     uint32_t *triCount, int leafMax, uint32_t nodeBase, const PtTri48 *leafTris, const int *bounds, float padScale)
 {
+	const float leafPad = leafTris ? __uint_as_float((unsigned int)bounds[6]) * padScale : 0.0f;  // as k_refit
 	__shared__ unsigned long long sWave[kBlock / PT_WAVE];
 	__shared__ uint32_t sBase[2];
 	const int n = bvh.n;
@@ -740,9 +756,36 @@ __global__ void __launch_bounds__(kBlock)
 	for (int s = 0; s < 4; ++s)
 		if (s < nSlots)
 		{
-			const float4 *b = reinterpret_cast<const float4 *>(boxes + 8 * (size_t)slot[s]);
-			blo[s] = b[0];
-			bhi[s] = b[1];
+			if (leafTris && slot[s] >= n - 1)
+			{
+				// LBVH, a child that is ONE triangle: k_refit does not store such a leaf's box (it travels through LDS); it is
+				// recomputed here from the leaf-ordered record (plane 2 = x, y, z order; sorted position = leaf slot), with
+				// k_refit's compares and padding
+				const PtTri48 t = leafTris[slot[s] - (n - 1)];
+				float l3[3], h3[3];
+#pragma unroll
+				for (int a = 0; a < 3; ++a)
+				{
+					float l = INFINITY, h = -INFINITY;
+					const float cs[3] = { t.v0[a], t.v1[a], t.v2[a] };
+#pragma unroll
+					for (int j = 0; j < 3; ++j)
+					{
+						if (cs[j] < l) l = cs[j];
+						if (cs[j] > h) h = cs[j];
+					}
+					l3[a] = l - leafPad;
+					h3[a] = h + leafPad;
+				}
+				blo[s] = make_float4(l3[0], l3[1], l3[2], 0.0f);
+				bhi[s] = make_float4(h3[0], h3[1], h3[2], 0.0f);
+			}
+			else
+			{
+				const float4 *b = reinterpret_cast<const float4 *>(boxes + 8 * (size_t)slot[s]);
+				blo[s] = b[0];
+				bhi[s] = b[1];
+			}
 			org[0] = fminf(org[0], blo[s].x);
 			org[1] = fminf(org[1], blo[s].y);
 			org[2] = fminf(org[2], blo[s].z);
@@ -1161,7 +1204,8 @@ hipError_t ptBuildBvh4(const PtBuildInput &in, PtBuildOutput &out, hipStream_t s
 				// a level cannot hold more wide nodes than 4^level: small grids for the top of the tree
 				const uint32_t cap = level < 10 ? divUp((size_t)1 << (2 * level), kBlock) : grid;
 				k_collapse_level<<<cap < grid ? cap : grid, kBlock, 0, stream>>>(tin, tout, counters + 8, level, view, boxes, vin, boxMode,
-				                                                                 leafPrim, nodes, counters + 1, leafMax, in.nodeBase);
+				                                                                 leafPrim, nodes, counters + 1, leafMax, in.nodeBase,
+				                                                                 (!ploc && !boxMode) ? tris + 2 * (size_t)n : nullptr, bounds, padScale);
 				CollapseTask *t = tin;
 				tin = tout;
 				tout = t;
