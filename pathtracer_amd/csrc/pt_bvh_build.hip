@@ -464,6 +464,27 @@ struct Bvh2View
 		const int j = reinterpret_cast<const int *>(topo + nd)[3];
 		return (uint32_t)(j > nd ? j - nd : nd - j) + 1u;
 	}
+	// children and leaf count of node nd with ONE load where the layout allows (LBVH: both come out of the 16-byte record)
+	__device__ __forceinline__ void load(int nd, int2 &k, uint32_t &c) const
+	{
+		k = make_int2(0, 0);
+		if (nd >= n - 1)
+		{
+			c = topo ? 1u : subCount[nd];
+			return;
+		}
+		if (topo)
+		{
+			const int4 r = topo[nd];
+			k = make_int2(r.x, r.y);
+			c = (uint32_t)(r.w > nd ? r.w - nd : nd - r.w) + 1u;
+		}
+		else
+		{
+			c = subCount[nd];
+			k = children[nd];
+		}
+	}
 	// LBVH only: first sorted position of the subtree
 	__device__ __forceinline__ uint32_t first(int nd) const
 	{
@@ -679,7 +700,9 @@ __global__ void __launch_bounds__(kBlock)
 	if (active)
 	{
 		task = tasksIn[ti];
-		const uint32_t rootCount = bvh.count(task.bvh2);
+		uint32_t rootCount;
+		int2 ch;
+		bvh.load(task.bvh2, ch, rootCount);
 		if ((int)rootCount <= leafMax)
 		{
 			slot[0] = task.bvh2;  // whole subtree is one leaf child
@@ -691,8 +714,11 @@ __global__ void __launch_bounds__(kBlock)
 			// slot[], cnt[], area[] are only ever indexed by unrolled loop counters (a run-time index would put them in
 			// scratch memory): "write entry s" is a select over the four entries
 			float area[4] = { -1.0f, -1.0f, -1.0f, -1.0f };
+			int2 kid[4] = { { 0, 0 }, { 0, 0 }, { 0, 0 }, { 0, 0 } };  // children of every slot: opening one costs no further load
 			auto put = [&](int s, int nd) {
-				const uint32_t c = bvh.count(nd);
+				uint32_t c;
+				int2 kk;
+				bvh.load(nd, kk, c);
 				const float ar = (int)c <= leafMax ? -1.0f : halfArea(boxes + 8 * (size_t)nd);  // leaf children are never opened
 #pragma unroll
 				for (int k = 0; k < 4; ++k)
@@ -701,16 +727,17 @@ __global__ void __launch_bounds__(kBlock)
 						slot[k] = nd;
 						cnt[k] = c;
 						area[k] = ar;
+						kid[k] = kk;
 					}
 			};
-			int2 ch = bvh.kids(task.bvh2);
 			put(0, ch.x);
 			put(1, ch.y);
 			nSlots = 2;
 #pragma unroll
 			for (int round = 0; round < 2; ++round)
 			{
-				int best = -1, bestNode = 0;
+				int best = -1;
+				int2 ch2 = make_int2(0, 0);
 				float bestArea = -1.0f;
 #pragma unroll
 				for (int k = 0; k < 4; ++k)
@@ -718,11 +745,10 @@ __global__ void __launch_bounds__(kBlock)
 					{
 						bestArea = area[k];
 						best = k;
-						bestNode = slot[k];
+						ch2 = kid[k];
 					}
 				if (best >= 0)  // otherwise every child is a leaf: nothing to open, in this round or the next
 				{
-					int2 ch2 = bvh.kids(bestNode);
 					put(best, ch2.x);
 					put(nSlots++, ch2.y);
 				}
