@@ -540,25 +540,45 @@ __global__ void __launch_bounds__(kBlock) k_refit(const float4 *triPos, const fl
 	const int base = blockIdx.x * kBlock, k = base + threadIdx.x;
 	sArrive[threadIdx.x] = 0;
 	__syncthreads();
-	if (k >= n) return;
+	const bool valid = k < n;
 	const float pad = __uint_as_float((unsigned int)bounds[6]) * padScale;  // 2^-18 * max|coord| for triangles
-	const uint32_t prim = sortedPrim[k];
+	const uint32_t prim = valid ? sortedPrim[k] : 0u;
 	int cur = (n - 1) + k;
-	int p = leafParent[k];
+	int p = valid ? leafParent[k] : -1;
 	float lo[3], hi[3];
-	if (triPos)
+	float4 r0 = make_float4(0, 0, 0, 0), r1 = r0, r2 = r0;
+	if (triPos)  // (uniform)
 	{
-		const float4 r0 = triPos[3 * (size_t)prim + 0], r1 = triPos[3 * (size_t)prim + 1], r2 = triPos[3 * (size_t)prim + 2];
+		if (valid)
+		{
+			r0 = triPos[3 * (size_t)prim + 0];
+			r1 = triPos[3 * (size_t)prim + 1];
+			r2 = triPos[3 * (size_t)prim + 2];
+		}
 		const float q[3][3] = { { r0.x, r0.y, r0.z }, { r0.w, r1.x, r1.y }, { r1.z, r1.w, r2.x } };
+		// The block's 256 records of a plane are 12 KB contiguous: staged through LDS (the box slots, not in use yet) so that
+		// every store instruction of a wave writes 1 KB of consecutive bytes -- written straight from the lanes, 16 bytes at
+		// a 48-byte stride, a store instruction touches 24 lines a third at a time.
+		float4 *stage = reinterpret_cast<float4 *>(&sBox[0][0]);
+		static_assert(sizeof(sBox) >= (size_t)kBlock * sizeof(PtTri48), "staging area");
+		const int nRec = n - base < kBlock ? n - base : kBlock;
 #pragma unroll
 		for (int r = 0; r < 3; ++r)
 		{
 			const int x = (r + 1) % 3, y = (r + 2) % 3, z = r;
-			float4 *dst = reinterpret_cast<float4 *>(tris + (size_t)r * n + k);
-			dst[0] = make_float4(q[0][x], q[0][y], q[0][z], q[1][x]);
-			dst[1] = make_float4(q[1][y], q[1][z], q[2][x], q[2][y]);
-			dst[2] = make_float4(q[2][z], __uint_as_float(prim), 0.0f, 0.0f);
+			stage[3 * threadIdx.x + 0] = make_float4(q[0][x], q[0][y], q[0][z], q[1][x]);
+			stage[3 * threadIdx.x + 1] = make_float4(q[1][y], q[1][z], q[2][x], q[2][y]);
+			stage[3 * threadIdx.x + 2] = make_float4(q[2][z], __uint_as_float(prim), 0.0f, 0.0f);
+			__syncthreads();
+			float4 *dst = reinterpret_cast<float4 *>(tris + (size_t)r * n + base);
+			for (int i = threadIdx.x; i < 3 * nRec; i += kBlock) dst[i] = stage[i];
+			__syncthreads();
 		}
+	}
+	if (!valid) return;
+	if (triPos)
+	{
+		const float q[3][3] = { { r0.x, r0.y, r0.z }, { r0.w, r1.x, r1.y }, { r1.z, r1.w, r2.x } };
 		// exactly k_tri_setup's box of the primitive (same compares in the same order)
 #pragma unroll
 		for (int a = 0; a < 3; ++a)
