@@ -165,3 +165,18 @@ def test_config5_shape_soup_tiles_pixel_sample(rt, pa, O):
     osc = O.OracleScene(sc.vertices, sc.indices, sc.materials, sc.mat_indices)
     want = osc.render_pixels(view, proj, W, H, px, gframe=1, spp_per_frame=2, max_depth=D, tmax=1e6, seed=21)
     assert np.array_equal(bits(whole.reshape(-1, 4)[px, :3]), bits(want))
+
+
+def test_fullsize_whole_frame_bit_exact(rt, pa, cornell, ocornell):
+    """The headline frame itself -- all 2 073 600 pixels of one 1920x1080 x 16 spp frame (a jittered one: global frame 2),
+    every bit against the oracle, and the ray count (the oracle traces ~10^8 rays for it: a few seconds on the box's cores)."""
+    view, proj = setup(rt, pa, cornell, seed=1)
+    rt.setFrameSchedule(first=2, stride=1)
+    rt.resetStats()
+    rt.raytrace(1)
+    img = rt.readImage()
+    rays = rt.stats().rays_total
+    px = np.arange(W * H, dtype=np.uint32)
+    want = ocornell.render_pixels(view, proj, W, H, px, gframe=2, spp_per_frame=S, max_depth=D, seed=1)
+    assert np.array_equal(bits(img.reshape(-1, 4)[:, :3]), bits(want))
+    assert W * H * S < rays <= W * H * S * D
