@@ -873,7 +873,8 @@ extern "C" int pt_build_accel(pt_ctx *c, int flags) try
 	}
 	// (two-level scenes: only on request -- a ray crosses many instance boxes there, and visiting the entry node's children
 	// in a fixed order instead of nearest first costs more than the wide first step saves: 64 x 64 grid 5.41 vs 5.78 Grays/s)
-	if (!c->brute && c->accel.nNodes && c->accel.nNodes <= (1u << 20) && !(flags & PT_ACCEL_NO_ENTRY_NODE) && !getenv("PT_NO_ENTRY") &&
+	if (!c->brute && c->accel.nNodes && (c->accel.nNodes <= (1u << 20) || getenv("PT_ENTRY_ANY_SIZE")) && !(flags & PT_ACCEL_NO_ENTRY_NODE) &&
+	    !getenv("PT_NO_ENTRY") &&
 	    (!c->tlasDepth || getenv("PT_ENTRY_TWO_LEVEL")))
 	{
 		// the tree top (two-level scenes: the top of the top-level tree) as one wide node that k_paths tests while it stages

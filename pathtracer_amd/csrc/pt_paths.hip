@@ -159,6 +159,10 @@ enum
 // box's 16 quads) -- there is no tree left to traverse, so no stack and no node step; the staging phase also tests the
 // FIRST leaf the ray's box test selects, at full lane utilisation, and only a ray with further candidates (one in three
 // on Cornell) is handed to a lane at all: the others go straight to the shading ring, or nowhere when they hit nothing.
+#ifndef PT_ENTRY_NEAREST
+#define PT_ENTRY_NEAREST 1
+#endif
+constexpr bool kEntryNearest = PT_ENTRY_NEAREST != 0;  // tree form: the lane enters the nearest hit child first
 enum
 {
 	PT_ENTRY_NONE = 0,
@@ -344,7 +348,7 @@ __global__ void __launch_bounds__(PT_WAVE) PT_PATHS_OCCUPANCY k_paths(PtPathsArg
 				sIn[10][lane] = pq;
 				if (kEntry)
 				{
-					sIn[kInEntry][lane] = pt_entry_test(sEntry, pr, tmin, tmax);
+					sIn[kInEntry][lane] = pt_entry_test<kEntryNearest>(sEntry, pr, tmin, tmax);
 					if (kStats) ++nodeFetches;  // one (wide) node visit
 				}
 				if (kInst)
@@ -644,8 +648,10 @@ __global__ void __launch_bounds__(PT_WAVE) PT_PATHS_OCCUPANCY k_paths(PtPathsArg
 					{
 						// the children of the entry node the ray hits (tested while it was staged): the first one now, the
 						// others when the traversal below it has emptied the stack (loop head); none: the ray misses the scene
-						pend = sIn[kInEntry][s];
-						cur = pend ? pt_entry_next(sEntry, pend) : PT_TRAVERSAL_DONE;
+						const uint32_t m = sIn[kInEntry][s];
+						pend = m & 0xFFFFu;
+						if (kEntryNearest && !kFlat) cur = pend ? pt_entry_first(sEntry, m, pend) : PT_TRAVERSAL_DONE;
+						else cur = pend ? pt_entry_next(sEntry, pend) : PT_TRAVERSAL_DONE;
 					}
 					if (kFlat)
 					{

@@ -267,6 +267,10 @@ __device__ __forceinline__ void pt_node_step(const PtSceneDev &sc, const PtLaneR
 // children it hits as a bit mask: child c is bit PT_ENTRY_WIDTH-1-c.  The lane that traverses the ray keeps the mask in a
 // register and visits the children one after the other, lowest bit first (pt_entry_next), each with the ordinary stack
 // discipline -- nothing is stored per child, and there is no limit on how many a ray may hit.
+// kNearest: bits 16..19 of the result also name the hit child the ray enters FIRST (bit position in the mask), for
+// pt_entry_first -- three more instructions per child; worth it where the children are subtrees (the order decides how
+// much the later ones are culled), not where they are leaves.
+template <bool kNearest = false>
 __device__ __forceinline__ uint32_t pt_entry_test(const uint4 *e, const PtLaneRay &ray, float tmin, float tmax)
 {
 	constexpr int W = PT_ENTRY_WIDTH, G = W / 4;
@@ -277,7 +281,7 @@ __device__ __forceinline__ uint32_t pt_entry_test(const uint4 *e, const PtLaneRa
 	const float bx = (h0.x - ray.ox) * ray.ix, by = (h0.y - ray.oy) * ray.iy, bz = (h0.z - ray.oz) * ray.iz;
 	const float4 *planes = rec + 2 + G;
 	const int nx = negx ? 3 * G : 0, ny = negy ? 3 * G : 0, nz = negz ? 3 * G : 0;
-	uint32_t mask = 0;
+	uint32_t mask = 0, nearest = 0xFFFFFFFFu;
 #pragma unroll
 	for (int g = 0; g < G; ++g)
 	{
@@ -303,9 +307,26 @@ __device__ __forceinline__ uint32_t pt_entry_test(const uint4 *e, const PtLaneRa
 			float t1 = fminf(fminf(tfx, tfy), fminf(tfz, tmax));
 			const bool hit = t0 <= t1 * 1.000001f;  // same test as a node step; an empty slot fails it whatever the ray
 			mask = (mask + mask) + (hit ? 1u : 0u);  // one add-with-carry per child
+			if (kNearest)
+			{
+				// entry distances are >= tmin >= 0, so their bit patterns order like unsigned integers; the low four bits
+				// carry the child's bit position instead of mantissa
+				const uint32_t key = hit ? ((__float_as_uint(t0) & ~15u) | (uint32_t)(W - 1 - (4 * g + c))) : 0xFFFFFFFFu;
+				nearest = key < nearest ? key : nearest;
+			}
 		}
 	}
-	return mask;
+	static_assert(!kNearest || W <= 16, "four bits for the nearest child");
+	return kNearest ? (mask | ((nearest & 15u) << 16)) : mask;
+}
+
+// The reference of the child a ray enters first (result `m` of pt_entry_test<true>, at least one child hit); `pend` gets the
+// other hit children.
+__device__ __forceinline__ uint32_t pt_entry_first(const uint4 *e, uint32_t m, uint32_t &pend)
+{
+	const uint32_t bit = (m >> 16) & 15u;
+	pend = (m & 0xFFFFu) & ~(1u << bit);
+	return reinterpret_cast<const uint32_t *>(e + 2)[(uint32_t)(PT_ENTRY_WIDTH - 1) - bit];
 }
 
 // The reference of the next child in `pend` (not zero), which it removes from the set.
