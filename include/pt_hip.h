@@ -73,11 +73,12 @@ typedef struct PtStats
 	uint32_t reserved;
 	double build_ms;            /* last pt_build_accel, device time */
 	/* Traversal work counters, only collected under PT_PROFILE_TRAVERSAL (instrumented kernel): */
-	uint64_t trav_nodes;        /* wide nodes fetched */
+	uint64_t trav_nodes;        /* wide nodes fetched (the entry node of the persistent pipeline counts as one per ray) */
 	uint64_t trav_tris;         /* ray/triangle tests */
 	uint64_t trav_hits;         /* rays that found a hit */
 	uint64_t trav_leaf_visits;  /* leaves entered (lane level) */
-	uint64_t trav_node_steps;   /* wave-level node steps: trav_nodes / (64 * trav_node_steps) = lane utilisation */
+	uint64_t trav_node_steps;   /* wave-level node steps of the traversal loop: trav_nodes / (64 * trav_node_steps) = lane
+	                               utilisation when the scene has no entry node (whose visits happen outside the loop) */
 	uint64_t trav_leaf_steps;   /* wave-level leaf steps (persistent pipeline only, like the two above) */
 	/* cmdCompactBlas's log line (VulkanRaytracing.cpp:247-256): bytes of the bottom-level structure (nodes, leaf
 	 * triangles, codes, order) after compaction and as the builder had to size it before knowing the node count */
