@@ -66,11 +66,15 @@ constexpr int kDoneRingFull = PT_DONE_RING;  // >= 64 entries; below 127 a retir
 #ifndef PT_INST_RING
 #define PT_INST_RING 96
 #endif
+#ifndef PT_INST_VOTE3
+#define PT_INST_VOTE3 0
+#endif
 #ifndef PT_INST_STACK
 #define PT_INST_STACK 12
 #endif
 constexpr int kDoneRingInst = PT_INST_RING;  // two-level scenes: their 1.8 KB of saved world rays cost occupancy otherwise
 constexpr int kStackLdsInst = PT_INST_STACK;
+constexpr bool kInstVote3 = PT_INST_VOTE3 != 0;
 constexpr int kDoneRingTiny = PT_DONE_RING_TINY;             // (only when more than 32 lanes retire at once onto more than 32 parked hits)
 // ring position p + i for p < kDoneRing, i <= kDoneRing (the ring length need not be a power of two)
 template <int kDoneRing>
@@ -699,8 +703,24 @@ __global__ void __launch_bounds__(PT_WAVE) PT_PATHS_OCCUPANCY k_paths(PtPathsArg
 		// One step for the LARGER of the two groups (majority-phase stepping, see pt_bounce.hip).
 		PT_T_MARK(PT_T_LOOP)
 		const unsigned long long nodeLanes = __ballot(!(cur & PT_LEAF_FLAG));
-		const unsigned long long leafLanes = __ballot((cur & PT_LEAF_FLAG) && cur != PT_TRAVERSAL_DONE);
-		const bool doNode = popcWave(nodeLanes) >= popcWave(leafLanes);
+		const bool atLeaf = (cur & PT_LEAF_FLAG) && cur != PT_TRAVERSAL_DONE;
+		bool doNode, mine = atLeaf;  // mine: this lane belongs to the leaf group that steps
+		if (kInst && kInstVote3)
+		{
+			// Two-level scenes have three leaf programs -- triangle leaf, instance entry (transform + ray preparation with its
+			// divisions), instance exit -- and a wave pays for each that any of its lanes needs: vote among THREE groups
+			// (nodes, triangle leaves, instance entries / exits) and run the largest.
+			const bool instOp = atLeaf && (cur == PT_INSTANCE_END || inst == PT_NO_INSTANCE);
+			const uint32_t nN = popcWave(nodeLanes), nT = popcWave(__ballot(atLeaf && !instOp)), nI = popcWave(__ballot(instOp));
+			doNode = nN >= nT && nN >= nI;
+			const bool doTri = !doNode && nT >= nI;
+			mine = atLeaf && (instOp != doTri);
+		}
+		else
+		{
+			const unsigned long long leafLanes = __ballot(atLeaf);
+			doNode = popcWave(nodeLanes) >= popcWave(leafLanes);
+		}
 		const PtLaneRay ray = { ox, oy, oz, ix, iy, iz, Sx, Sy, Sz, kpack };
 		if (kStats)
 		{
@@ -713,7 +733,7 @@ __global__ void __launch_bounds__(PT_WAVE) PT_PATHS_OCCUPANCY k_paths(PtPathsArg
 			if (kStats) ++nodeFetches;
 			pt_node_step<kStackLds, kNodeMode>(sc, ray, tmin, best, cur, sp, sStack, lane, mySpill, a.spillStride, sNodes);
 		}
-		if (!doNode && (cur & PT_LEAF_FLAG) && cur != PT_TRAVERSAL_DONE)
+		if (!doNode && mine)
 		{
 			if (kInst && cur == PT_INSTANCE_END)
 			{
