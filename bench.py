@@ -60,8 +60,10 @@ def parse(argv=None):
     ap.add_argument("--builder", choices=["ploc", "lbvh"], default="ploc", help="BVH2 construction before the BVH4 collapse")
     ap.add_argument("--split", choices=["streams", "tiles"], default="streams",
                     help="multi-GPU partitioning: disjoint sample streams (frames) or image tiles (column strips)")
-    ap.add_argument("--scene", choices=["cornell", "soup"], default="cornell",
-                    help="cornell = BASELINE configs[1] (the metric); soup = the procedural triangles of configs[4]")
+    ap.add_argument("--scene", choices=["cornell", "soup", "viking", "teapot"], default="cornell",
+                    help="cornell = BASELINE configs[1] (the metric); soup = the procedural triangles of configs[4]; viking = "
+                         "configs[2] (viking_room.obj with a 1024^2 diffuse map, use --width 3840 --height 2160); teapot = configs[3] "
+                         "(teapot.obj x 64x64 instances) -- both meshes from tests/golden/ref_seam.npz, one light quad added")
     ap.add_argument("--tris", type=float, default=1e6, help="--scene soup: number of triangles")
     ap.add_argument("--force-dist", action="store_true",
                     help="go through torch.distributed/RCCL even for one rank (rehearses the N>1 path on one GPU)")
@@ -165,13 +167,42 @@ def load_profile_json(name):
     return d
 
 
+def reference_mesh(pa, name):
+    """The reference's models/<name>.obj as its own tinyobjloader read it (oracle/_ref dump in tests/golden/ref_seam.npz),
+    through the product's loadModel half."""
+    import numpy as np
+    z = np.load(os.path.join(ROOT, "tests", "golden", "ref_seam.npz"))
+    return pa.scene_from_tinyobj(*(z[f"{name}_{k}"] for k in ("v", "vn", "vt", "idx", "mid", "mat")))
+
+
 def build_scene(a, pa):
-    """(scene, view, proj, tmax, description)"""
+    """(scene, view, proj, tmax, description); a.instances / a.texture are set for the scenes that have them"""
     import math
+    import numpy as np
     W, H = a.width, a.height
+    a.instances = a.texture = None
     if a.scene == "cornell":
         view, proj = pa.reference_camera(W, H)
         return pa.scenes.cornell_box(), view, proj, 1e4, "Cornell box"
+    if a.scene == "viking":
+        # neither mesh comes with a .mtl or an emitter in the reference (all grey, black image): one light quad is added
+        sc = pa.scenes.with_light_quad(reference_mesh(pa, "viking_room"),
+                                       [[-2.0, -2.0, 2.0], [2.0, -2.0, 2.0], [2.0, 2.0, 2.0], [-2.0, 2.0, 2.0]], (0, 0, -1))
+        a.texture = np.random.default_rng(3).integers(0, 256, (1024, 1024, 4), dtype=np.uint8)  # the size of textures/viking_room.png
+        view = pa.look_at((1.3, 1.3, 1.2), (0.05, 0.0, 0.3), (0.0, 0.0, 1.0))
+        proj = pa.perspective(math.radians(45.0), W / H, 0.1, 10.0)
+        proj[5] *= -1
+        return sc, view, proj, 1e4, f"viking_room.obj ({sc.n_tris} triangles) with a 1024x1024 diffuse map"
+    if a.scene == "teapot":
+        sc = pa.scenes.with_light_quad(reference_mesh(pa, "teapot"),
+                                       [[-3.0, 5.0, -3.0], [3.0, 5.0, -3.0], [3.0, 5.0, 3.0], [-3.0, 5.0, 3.0]], (0, -1, 0))
+        n = 64
+        ext = 8.0 * n
+        a.instances = pa.scenes.instance_grid(n, 8.0)
+        view = pa.look_at((0.0, 0.45 * ext, 0.8 * ext), (0.0, 0.0, 0.0), (0, 1, 0))
+        proj = pa.perspective(math.radians(45.0), W / H, 0.1, 10.0 * ext)
+        proj[5] *= -1
+        return sc, view, proj, 1e6, f"teapot.obj ({sc.n_tris} triangles) x {n}x{n} instances = {n * n * sc.n_tris / 1e6:.1f} M instanced triangles"
     n = int(a.tris)
     extent = 1000.0 * (n / 1e8) ** (1.0 / 3.0)  # the density of configs[4]: 1e8 triangles in a 1000^3 cube
     sc = pa.scenes.random_triangles(n, extent=extent, edge=1.0)
@@ -219,8 +250,12 @@ def main():
     W, H, S, D = a.width, a.height, a.spp_per_frame, a.depth
     scene, view, proj, tmax, scene_name = build_scene(a, pa)
     rt = pa.HipRaytracing(local_rank)
+    if a.instances is not None:
+        rt.setInstances(a.instances)
     rt.buildBlas(scene, pa.api.PT_ACCEL_BVH4_PLOC if a.builder == "ploc" else pa.api.PT_ACCEL_BVH4)
     rt.buildTlas()
+    if a.texture is not None:
+        rt.setTexture(a.texture)
     rt.resize(W, H)
     rt.setCamera(view, proj)
     rt.setParams(spp_per_frame=S, max_depth=D, tmin=1e-3, tmax=tmax, seed=0, max_frames=0)
@@ -272,7 +307,9 @@ def main():
                                               if ts.trav_leaf_visits <= 64.0 * ts.trav_leaf_steps else None),
                       "node_steps_per_64_rays": round(64.0 * ts.trav_node_steps / rays_stat, 3),
                       "leaf_steps_per_64_rays": round(64.0 * ts.trav_leaf_steps / rays_stat, 3),
-                      "leaf_visits_per_ray": round(ts.trav_leaf_visits / rays_stat, 3)}
+                      "leaf_visits_per_ray": round(ts.trav_leaf_visits / rays_stat, 3),
+                      "note": "with an entry node (default for trees up to 2^20 nodes) trav_nodes includes one visit per ray made "
+                              "in the staging phase, outside the counted node steps"}
     rt.setProfiling(0)
 
     # ---- warmup ----
@@ -381,8 +418,8 @@ def main():
             "scaling": "strong" if tiles else "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": f"{scene_name} {W}x{H}, {S} spp/frame x {a.steps} frames"
                                    f"{'' if tiles else '/GPU'}, max depth {D}, persistent wavefront path tracer, quantised BVH4 "
-                                   f"({a.builder.upper()})" + (" (BASELINE.json configs[1])" if a.scene == "cornell" else
-                                                               " (BASELINE.json configs[4] generator)"),
+                                   f"({a.builder.upper()})" + {"cornell": " (BASELINE.json configs[1])", "soup": " (BASELINE.json configs[4] generator)",
+                                                             "viking": " (BASELINE.json configs[2])", "teapot": " (BASELINE.json configs[3])"}[a.scene],
                        "width": W, "height": H, "spp_per_frame": S, "max_depth": D, "total_spp": total_spp,
                        "parallelism": (f"image tiles (column strips) x{world}" if tiles else f"sample-stream x{world}")},
             "samples_per_px_per_s": round(total_spp / dt_max, 3),
