@@ -181,3 +181,42 @@ def test_random_small_scenes_every_form_and_pipeline(rt, pa, O, seed):
         assert st.rays_total == rays, (name, seed)
         assert np.array_equal(bits(img), bits(want)), (name, seed, sc.n_tris)
     rt.setPipeline(PT_PIPELINE_PERSISTENT)
+
+
+def test_rays_along_shared_edges_do_not_leak(rt, pa, O):
+    """Watertightness where it is hardest: with an odd image extent and an axis-aligned camera the centre column and the centre
+    row of pixel-centre rays (global frame 0) have a direction component that is exactly zero and run exactly along the shared
+    edges x = 0 and z = 0 of a flat, emissive grid mesh (and through its vertices): an edge function is exactly 0 there, the
+    double-precision fall-back of the watertight test decides, and no ray may slip between two triangles.  Every pipeline and
+    every entry-node form against the oracle, bit for bit; the centre lines inside the mesh are lit without a gap."""
+    from pathtracer_amd.api import (PT_ACCEL_BVH4, PT_ACCEL_BVH4_PLOC, PT_ACCEL_NO_ENTRY_NODE, PT_PIPELINE_FUSED,
+                                    PT_PIPELINE_PERSISTENT, PT_PIPELINE_SPLIT)
+    g = pa.scenes.grid_mesh(8, 8, size=2.0, amplitude=0.0)
+    n_mesh = 2 * 8 * 8
+    mats = np.array([[0.5, 0.5, 0.5, 7.0, 7.0, 7.0]], dtype=np.float32)  # everything emits: a hit pixel is exactly 7
+    sc = pa.Scene(g.vertices[:81], g.indices[:3 * n_mesh], mats, np.zeros(n_mesh, np.uint32))
+    osc = O.OracleScene(sc.vertices, sc.indices, sc.materials, sc.mat_indices)
+    W = H = 65
+    view = pa.look_at((0.0, 3.0, 0.0), (0.0, 0.0, 0.0), (0.0, 0.0, -1.0))
+    proj = pa.perspective(np.radians(45.0), 1.0, 0.1, 100.0)
+    proj[5] *= -1
+    want, rays = osc.render(view, proj, W, H, frames=1, spp_per_frame=2, max_depth=3, seed=0)
+    ohits = osc.primary_hits(view, proj, W, H)
+    prim = ohits["prim"].reshape(H, W)
+    inside = np.abs(np.linspace(-1, 1, W) * 3.0 * np.tan(np.radians(22.5))) < 0.99  # pixel centres over the mesh
+    assert inside.sum() > 40
+    assert np.all(prim[H // 2, inside] != 0xFFFFFFFF) and np.all(prim[inside, W // 2] != 0xFFFFFFFF)
+    assert np.all(want[H // 2, inside, :3] == 7.0) and np.all(want[inside, W // 2, :3] == 7.0)
+    cases = [(PT_ACCEL_BVH4_PLOC, None, PT_PIPELINE_PERSISTENT), (PT_ACCEL_BVH4, {"PT_NO_QUADS": "1"}, PT_PIPELINE_PERSISTENT),
+             (PT_ACCEL_BVH4_PLOC | (1 << 8), None, PT_PIPELINE_PERSISTENT),
+             (PT_ACCEL_BVH4_PLOC | PT_ACCEL_NO_ENTRY_NODE, None, PT_PIPELINE_PERSISTENT),
+             (PT_ACCEL_BVH4_PLOC, None, PT_PIPELINE_FUSED), (PT_ACCEL_BVH4, None, PT_PIPELINE_SPLIT)]
+    for flags, env, pipe in cases:
+        rt.setPipeline(pipe)
+        res = _render(rt, pa, sc, view, proj, W, H, flags, env, frames=1, spp=2, depth=3, seed=0, profile=False)
+        img, st = res[0]
+        assert st.rays_total == rays, (flags, env, pipe)
+        assert np.array_equal(bits(img), bits(want)), (flags, env, pipe)
+        hits = rt.debugPrimaryHits()
+        assert np.array_equal(hits["prim"], ohits["prim"]) and np.array_equal(bits(hits["t"]), bits(ohits["t"]))
+    rt.setPipeline(PT_PIPELINE_PERSISTENT)
