@@ -342,33 +342,45 @@ __global__ void __launch_bounds__(PT_WAVE) PT_PATHS_OCCUPANCY k_paths(PtPathsArg
 	auto stage = [&](bool valid, float3x o, float3x d, uint32_t depth, uint32_t pq) -> uint32_t {
 		if (!kFlat)
 		{
+			// With an entry node a ray whose box test selects no child has missed the scene: it is finished here (rmiss adds
+			// nothing) and never takes a lane; the others are ballot-packed.  Without one every valid ray is kept (the valid
+			// lanes are 0 .. n-1, so the rank is the lane).
+			PtLaneRay pr = {};
+			uint32_t m = 0;
 			if (valid)
 			{
-				PtLaneRay pr = pt_prepare_ray<true>(o, d);  // every lane of the staging batch is here: the shared-reciprocal form
-				sIn[0][lane] = __float_as_uint(pr.ox);
-				sIn[1][lane] = __float_as_uint(pr.oy);
-				sIn[2][lane] = __float_as_uint(pr.oz);
-				sIn[3][lane] = __float_as_uint(pr.ix);
-				sIn[4][lane] = __float_as_uint(pr.iy);
-				sIn[5][lane] = __float_as_uint(pr.iz);
-				sIn[6][lane] = __float_as_uint(pr.Sx);
-				sIn[7][lane] = __float_as_uint(pr.Sy);
-				sIn[8][lane] = __float_as_uint(pr.Sz);
-				sIn[9][lane] = pr.kpack | (depth << 16);
-				sIn[10][lane] = pq;
+				pr = pt_prepare_ray<true>(o, d);  // every lane of the staging batch is here: the shared-reciprocal form
 				if (kEntry)
 				{
-					sIn[kInEntry][lane] = pt_entry_test<kEntryNearest>(sEntry, pr, tmin, tmax);
+					m = pt_entry_test<kEntryNearest>(sEntry, pr, tmin, tmax);
 					if (kStats) ++nodeFetches;  // one (wide) node visit
 				}
+			}
+			const bool keep = valid && (!kEntry || (m & 0xFFFFu) != 0u);
+			const unsigned long long km = __ballot(keep);
+			if (keep)
+			{
+				const uint32_t r = kEntry ? popc64(km & lanesBelow) : (uint32_t)lane;
+				sIn[0][r] = __float_as_uint(pr.ox);
+				sIn[1][r] = __float_as_uint(pr.oy);
+				sIn[2][r] = __float_as_uint(pr.oz);
+				sIn[3][r] = __float_as_uint(pr.ix);
+				sIn[4][r] = __float_as_uint(pr.iy);
+				sIn[5][r] = __float_as_uint(pr.iz);
+				sIn[6][r] = __float_as_uint(pr.Sx);
+				sIn[7][r] = __float_as_uint(pr.Sy);
+				sIn[8][r] = __float_as_uint(pr.Sz);
+				sIn[9][r] = pr.kpack | (depth << 16);
+				sIn[10][r] = pq;
+				if (kEntry) sIn[kInEntry][r] = m;
 				if (kInst)
 				{
-					sIn[kInDir + 0][lane] = __float_as_uint(d.x);
-					sIn[kInDir + 1][lane] = __float_as_uint(d.y);
-					sIn[kInDir + 2][lane] = __float_as_uint(d.z);
+					sIn[kInDir + 0][r] = __float_as_uint(d.x);
+					sIn[kInDir + 1][r] = __float_as_uint(d.y);
+					sIn[kInDir + 2][r] = __float_as_uint(d.z);
 				}
 			}
-			return popcWave(__ballot(valid));  // valid lanes are 0 .. n-1
+			return popcWave(km);
 		}
 		// flat scene: box test and the first leaf here, with all 64 lanes; then the ray is finished (hit: parked for the
 		// shading pass; nothing hit: gone) or goes -- ballot-packed -- to the staging area with what it has found so far
@@ -613,8 +625,8 @@ __global__ void __launch_bounds__(PT_WAVE) PT_PATHS_OCCUPANCY k_paths(PtPathsArg
 							flush(PT_WAVE);
 							__syncthreads();
 						}
-						if (staged == 0) continue;  // none of the batch needs a lane: stage the next one
 					}
+					if (kEntry && staged == 0) continue;  // none of the batch needs a lane: stage the next one
 					PT_T_MARK(PT_T_TAKE)
 				}
 				uint32_t avail = inCount - inPos, want = popcWave(idle);
