@@ -328,6 +328,12 @@ const uint32_t *pt_scene_indices(const PtSceneData *s);
 const PtMaterial *pt_scene_materials(const PtSceneData *s);
 const uint32_t *pt_scene_mat_indices(const PtSceneData *s);
 const char *pt_scene_warnings(const PtSceneData *s);
+/* tinyobj::material_t::diffuse_texname (the MTL file's `map_Kd [-options] file`, tiny_obj_loader.h:1204-1208) of one
+ * material, relative names resolved against the OBJ's directory; "" when the material has none or the index is out of
+ * range.  The reference's loadModel never reads it (main.cpp:1125-1133 takes only diffuse and emission), which is why
+ * models/viking_room renders untextured there; pt_render and HipRaytracing.setTextureFromScene hand it to pt_set_texture
+ * (SURVEY.md 8(f) row 3).  The pointer lives as long as the PtSceneData. */
+const char *pt_scene_diffuse_map(const PtSceneData *s, uint32_t material);
 
 /* glm::lookAt / glm::perspective (RH, -1..1 depth: SURVEY.md section 0) / glm::inverse as the
  * reference's host uses them, and the fixed camera of main.cpp:1465-1480 (incl. proj[1][1]*=-1). */

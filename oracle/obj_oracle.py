@@ -174,12 +174,37 @@ def _sscanf_s(s: str) -> str:
     return s.split()[0] if s.split() else ""
 
 
+_TEX_OPTION_WORDS = {"-blendu": 1, "-blendv": 1, "-clamp": 1, "-boost": 1, "-bm": 1, "-type": 1, "-imfchan": 1, "-texres": 1,
+                     "-mm": 2, "-o": 3, "-s": 3, "-t": 3}
+
+
+def texture_name(rest: str) -> str:
+    """ParseTextureNameAndOption (tiny_obj_loader.h:757-850) for its file name only: options are skipped with their
+    arities, the last plain word is the name.  (-o/-s/-t take three numbers there; one to three here, as the MTL
+    specification allows, never the last word of the statement.)"""
+    words = rest.split()
+    name, i = "", 0
+    while i < len(words):
+        n = _TEX_OPTION_WORDS.get(words[i])
+        if n is None:
+            name = words[i]
+        elif n < 3:
+            i += n
+        else:
+            k = 0
+            while k < 3 and i + 2 < len(words) and words[i + 1][0] in "+-.0123456789":
+                i += 1
+                k += 1
+        i += 1
+    return name
+
+
 def parse_mtl(text: str, materials: list, material_map: dict):
     """LoadMtl (tiny_obj_loader.h:965-1330) restricted to name/diffuse/emission."""
-    cur = {"name": "", "diffuse": [np.float32(0)] * 3, "emission": [np.float32(0)] * 3}
-
     def fresh():
-        return {"name": "", "diffuse": [np.float32(0)] * 3, "emission": [np.float32(0)] * 3}
+        return {"name": "", "diffuse": [np.float32(0)] * 3, "emission": [np.float32(0)] * 3, "diffuse_texname": ""}
+
+    cur = fresh()
 
     for line in _lines(text):
         line = line.rstrip(" \t")
@@ -200,6 +225,9 @@ def parse_mtl(text: str, materials: list, material_map: dict):
             tok.i = 2
             rgb = [tok.real(), tok.real(), tok.real()]
             cur["diffuse" if t[1] == "d" else "emission"] = rgb
+            continue
+        if t.startswith("map_Kd") and len(t) > 6 and t[6] in " \t":
+            cur["diffuse_texname"] = texture_name(t[7:])
             continue
     material_map.setdefault(cur["name"], len(materials))
     materials.append(cur)
@@ -295,8 +323,15 @@ def parse_obj(path: str):
 
 def load_model(path: str):
     """PathTracer::loadModel (main.cpp:1101-1190).  Returns dict of numpy arrays:
-    vertices (n,11) f32, indices (m,) u32, materials (k,6) f32, mat_indices (m/3,) u32."""
-    return model_from_tinyobj(parse_obj(path))
+    vertices (n,11) f32, indices (m,) u32, materials (k,6) f32, mat_indices (m/3,) u32, diffuse_maps (k strings)."""
+    obj = parse_obj(path)
+    model = model_from_tinyobj(obj)
+    # material_t::diffuse_texname, which loadModel itself never reads: relative names against the OBJ's directory
+    base = os.path.dirname(path)
+    mtl_dir = (base if base else "") + "/"
+    model["diffuse_maps"] = tuple(
+        (t if not t or t[0] == "/" else mtl_dir + t) for t in (m.get("diffuse_texname", "") for m in obj["materials"])) + ("",)  # the grey fallback material has none
+    return model
 
 
 def tinyobj_from_arrays(vertices, normals, texcoords, indices, material_ids, materials):

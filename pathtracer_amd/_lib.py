@@ -91,6 +91,7 @@ SYMBOLS = {
     "pt_scene_materials": (_vp, [_vp]),
     "pt_scene_mat_indices": (_vp, [_vp]),
     "pt_scene_warnings": (C.c_char_p, [_vp]),
+    "pt_scene_diffuse_map": (C.c_char_p, [_vp, C.c_uint32]),
     "pt_look_at": (None, [_vp, _vp, _vp, _vp]),
     "pt_perspective": (None, [_f, _f, _f, _f, _vp]),
     "pt_inverse4": (None, [_vp, _vp]),

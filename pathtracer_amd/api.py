@@ -45,6 +45,7 @@ class Scene:
     materials: np.ndarray     # (k, 6) float32: diffuse3 emission3         (24 B records)
     mat_indices: np.ndarray   # (m/3,) uint32
     warnings: str = ""
+    diffuse_maps: tuple = ()  # per material: path of its map_Kd image, or ""
 
     def __post_init__(self):
         self.vertices = np.ascontiguousarray(self.vertices, dtype=np.float32).reshape(-1, 11)
@@ -102,7 +103,8 @@ def _scene_from_handle(L, h) -> Scene:
                      view(L.pt_scene_indices(h), np.uint32, ni),
                      view(L.pt_scene_materials(h), np.float32, nm * 6).reshape(-1, 6),
                      view(L.pt_scene_mat_indices(h), np.uint32, ni // 3),
-                     L.pt_scene_warnings(h).decode())
+                     L.pt_scene_warnings(h).decode(),
+                     tuple(L.pt_scene_diffuse_map(h, m).decode() for m in range(nm)))
     finally:
         L.pt_scene_free(h)
 
@@ -274,6 +276,15 @@ class HipRaytracing:
         t = np.ascontiguousarray(rgba8, dtype=np.uint8)
         assert t.ndim == 3 and t.shape[2] == 4
         self._check(self._L.pt_set_texture(self._ctx, _p(t), t.shape[1], t.shape[0]))
+
+    def setTextureFromScene(self, scene: "Scene"):
+        """The first map_Kd image the scene's MTL file names and that exists (what pt_render does without -tex); returns
+        its path, or None (texture left as it was) when there is none.  One texture slot: pt_set_texture."""
+        for path in scene.diffuse_maps:
+            if path and os.path.isfile(path):
+                self.setTexture(load_png(path))
+                return path
+        return None
 
     def buildTlas(self):
         """VulkanRaytracing::buildTlas (VulkanRaytracing.cpp:448-527): one identity instance -- nothing

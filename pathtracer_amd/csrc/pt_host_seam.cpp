@@ -36,6 +36,7 @@ struct PtSceneData
 	std::vector<uint32_t> indices;
 	std::vector<PtMaterial> materials;
 	std::vector<uint32_t> matIndices;
+	std::vector<std::string> diffuseMaps;  // per material: path of its map_Kd image (relative names resolved against the OBJ's directory), or empty
 	std::string warnings;
 };
 
@@ -232,7 +233,38 @@ struct MtlEntry
 	std::string name;
 	float kd[3] = { 0, 0, 0 };
 	float ke[3] = { 0, 0, 0 };
+	std::string mapKd;  // map_Kd: tinyobj's material_t::diffuse_texname (which the reference never reads)
 };
+
+// File name of a `map_Kd [-option args ...] name` statement: options are skipped with the arities of the MTL specification
+// (tinyobjloader's ParseTextureNameAndOption), the last plain word is the name.
+std::string textureName(const char *t)
+{
+	std::vector<std::string> words;
+	while (*t)
+	{
+		while (isBlank(*t)) ++t;
+		const char *b = t;
+		while (*t && !isBlank(*t)) ++t;
+		if (t > b) words.push_back(std::string(b, t));
+	}
+	std::string name;
+	for (size_t i = 0; i < words.size(); ++i)
+	{
+		const std::string &w = words[i];
+		if (w == "-blendu" || w == "-blendv" || w == "-clamp" || w == "-imfchan" || w == "-type" || w == "-boost" || w == "-bm" ||
+		    w == "-texres")
+			i += 1;
+		else if (w == "-mm") i += 2;
+		else if (w == "-o" || w == "-s" || w == "-t")
+		{
+			// one to three numbers; the last word of the statement is always the name
+			for (int k = 0; k < 3 && i + 2 < words.size() && strchr("+-.0123456789", words[i + 1][0]); ++k) ++i;
+		}
+		else name = w;
+	}
+	return name;
+}
 
 void parseMtl(const std::string &text, std::vector<MtlEntry> &mats, std::map<std::string, int> &byName)
 {
@@ -263,6 +295,11 @@ void parseMtl(const std::string &text, std::vector<MtlEntry> &mats, std::map<std
 			dst[0] = readReal(c);
 			dst[1] = readReal(c);
 			dst[2] = readReal(c);
+			continue;
+		}
+		if (strncmp(t, "map_Kd", 6) == 0 && isBlank(t[6]))
+		{
+			cur.mapKd = textureName(t + 7);
 			continue;
 		}
 	}
@@ -553,6 +590,8 @@ extern "C" int pt_load_obj(const char *obj_path, PtSceneData **out) try
 	}
 	PtSceneData *sd = new PtSceneData();
 	sd->warnings = warnings;
+	for (const MtlEntry &m : mtl)
+		sd->diffuseMaps.push_back(m.mapKd.empty() || m.mapKd[0] == '/' ? m.mapKd : mtlDir + m.mapKd);
 	int rc = loadModelFromArrays("pt_load_obj", v, vn, vt, corners, materialIds, mats, sd);
 	if (rc)
 	{
@@ -616,6 +655,10 @@ extern "C" const uint32_t *pt_scene_indices(const PtSceneData *s) { return s->in
 extern "C" const PtMaterial *pt_scene_materials(const PtSceneData *s) { return s->materials.data(); }
 extern "C" const uint32_t *pt_scene_mat_indices(const PtSceneData *s) { return s->matIndices.data(); }
 extern "C" const char *pt_scene_warnings(const PtSceneData *s) { return s->warnings.c_str(); }
+extern "C" const char *pt_scene_diffuse_map(const PtSceneData *s, uint32_t material)
+{
+	return (s && material < s->diffuseMaps.size()) ? s->diffuseMaps[material].c_str() : "";
+}
 
 // ---------------------------------------------------------------------------- camera ----
 // Column-major float[16] (element (column c, row r) at [4c + r]), the memory layout of glm::mat4

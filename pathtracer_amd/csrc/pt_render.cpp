@@ -3,6 +3,7 @@
 // without the window: loads an OBJ, renders N frames, writes the accumulation image.
 //
 //   pt_render scene.obj [-w 800] [-h 600] [-spp 10] [-frames 100] [-depth 20] [-seed 0] [-tex map.png]
+//             (default: the first map_Kd of the OBJ's MTL file; `-tex none` renders untextured)
 //             [-o out.pfm|out.ppm|out.png] [-gpus G] [-devices 0,1,..] [-split streams|tiles]
 //
 // Defaults are the reference's constants (VulkanUtils.h:11-15, raytrace.rgen:22-23).
@@ -157,6 +158,20 @@ int main(int argc, char **argv)
 	CHECK(pt_load_obj(objPath.c_str(), &sd));
 	if (*pt_scene_warnings(sd)) fprintf(stderr, "%s", pt_scene_warnings(sd));
 	base.sd = sd;
+	// no -tex: the first material's map_Kd, when the MTL names one and the file is there (one texture slot: pt_set_texture)
+	for (uint32_t m = 0; base.texPath.empty() && m < pt_scene_n_materials(sd); ++m)
+	{
+		const char *map = pt_scene_diffuse_map(sd, m);
+		if (!*map) continue;
+		if (FILE *f = fopen(map, "rb"))
+		{
+			fclose(f);
+			base.texPath = map;
+			fprintf(stderr, "diffuse map %s (map_Kd of material %u)\n", map, m);
+		}
+		else fprintf(stderr, "WARN: map_Kd %s of material %u not found\n", map, m);
+	}
+	if (base.texPath == "none") base.texPath.clear();
 	const uint32_t W = base.W, H = base.H;
 	const bool tiles = split == "tiles";
 	const int perGpu = tiles ? base.frames : (base.frames + gpus - 1) / gpus;

@@ -96,6 +96,50 @@ def test_pt_render_one_and_two_contexts(pa, tmp_path):
     assert os.path.getsize(out3) > 100
 
 
+def test_pt_render_loads_the_map_kd_of_the_mtl(pa, tmp_path):
+    """An OBJ whose MTL names a diffuse map (map_Kd; tinyobj's diffuse_texname, which the reference parses and never uses):
+    pt_render samples it without -tex, exactly as the API does after setTextureFromScene; `-tex none` renders the untextured
+    image, which differs."""
+    rng = np.random.default_rng(5)
+    tex = rng.integers(0, 256, size=(8, 16, 4), dtype=np.uint8)
+    tex[..., 3] = 255
+    (tmp_path / "tex").mkdir()
+    pa.write_png(str(tmp_path / "tex" / "checks.png"), tex)
+    (tmp_path / "wall.mtl").write_text("newmtl lamp\nKd 0 0 0\nKe 4 4 4\nnewmtl wall\nKd 1 1 1\nmap_Kd -clamp off tex/checks.png\n")
+    (tmp_path / "wall.obj").write_text(
+        "mtllib wall.mtl\n"
+        "v -1.5 0 -1\nv 1.5 0 -1\nv 1.5 2.5 -1\nv -1.5 2.5 -1\n"  # wall in front of pt_reference_camera's eye (0, 1, 3.5), facing it
+        "v -2 -1 5\nv -2 3 5\nv 2 3 5\nv 2 -1 5\n"                # lamp behind the eye, facing the wall
+        "vt 0 0\nvt 1 0\nvt 1 1\nvt 0 1\nvn 0 0 1\nvn 0 0 -1\n"
+        "usemtl wall\nf 1/1/1 2/2/1 3/3/1 4/4/1\nusemtl lamp\nf 5/1/2 6/2/2 7/3/2 8/4/2\n")
+    obj = str(tmp_path / "wall.obj")
+    scene = pa.load_obj(obj)
+    assert scene.diffuse_maps == ("", str(tmp_path) + "/tex/checks.png", "")
+    W, H, spp, depth, seed, frames = 48, 32, 4, 4, 3, 2
+    common = [obj, "-w", str(W), "-h", str(H), "-spp", str(spp), "-depth", str(depth), "-seed", str(seed), "-frames", str(frames)]
+    out_t, out_n = str(tmp_path / "t.pfm"), str(tmp_path / "n.pfm")
+    run(common + ["-o", out_t])
+    run(common + ["-tex", "none", "-o", out_n])
+
+    def api(textured):
+        rt = pa.HipRaytracing(0)
+        rt.buildBlas(scene)
+        if textured:
+            assert rt.setTextureFromScene(scene) == scene.diffuse_maps[1]
+        rt.resize(W, H)
+        rt.setCamera(*pa.reference_camera(W, H))
+        rt.setParams(spp_per_frame=spp, max_depth=depth, seed=seed, max_frames=frames)
+        rt.raytrace(frames)
+        img = rt.readImage()
+        rt.cleanup()
+        return img
+
+    want_t, want_n = api(True), api(False)
+    assert np.array_equal(bits(read_pfm(out_t)), bits(want_t[..., :3]))
+    assert np.array_equal(bits(read_pfm(out_n)), bits(want_n[..., :3]))
+    assert want_n[..., :3].max() > 0 and not np.array_equal(want_t, want_n)
+
+
 def test_pt_render_rejects_bad_arguments(tmp_path, pa):
     obj = pa.scenes.write_cornell_box(str(tmp_path))
     for extra in (["-gpus", "0"], ["-gpus", "2", "-devices", "0"], ["-split", "rows"], ["-gpus", "1", "-devices", "99"]):

@@ -173,6 +173,36 @@ def test_loader_edge_cases_product_equals_oracle(pa, tmp_path, newline):
     assert got.vertices[0, 9] == 0.25 and got.vertices[0, 10] == 0.25  # V flipped: 1 - 0.75
 
 
+def test_loader_map_kd_product_equals_oracle(pa, tmp_path):
+    """tinyobj's material_t::diffuse_texname (ParseTextureNameAndOption, tiny_obj_loader.h:757-850): options skipped with
+    their arities, relative names resolved against the OBJ's directory, absolute names kept."""
+    import obj_oracle as oo
+    mtl = ("newmtl a\nKd 1 1 1\nmap_Kd wood.png\n"
+           "newmtl b\nmap_Kd -clamp on -s 2 2 1 -o 0.5 0 0 -mm 0 1 -imfchan r tex/brick.png\nKd 0.5 0.5 0.5\n"
+           "newmtl c\nKd 0 1 0\nmap_Ka notthis.png\n"
+           "newmtl d\nmap_Kd\t-blendu off /abs/olute.png \nmap_Bump -bm 2 bump.png\n"
+           "newmtl e\nmap_Kd -s 4 tile.png\n")
+    p = tmp_path / "maps.obj"
+    p.write_text("mtllib maps.mtl\nv 0 0 0\nv 1 0 0\nv 0 1 0\nvn 0 0 1\nusemtl b\nf 1//1 2//1 3//1\n")
+    (tmp_path / "maps.mtl").write_text(mtl)
+    got, want = pa.load_obj(str(p)), oo.load_model(str(p))
+    d = str(tmp_path) + "/"
+    assert got.diffuse_maps == (d + "wood.png", d + "tex/brick.png", "", "/abs/olute.png", d + "tile.png", "")
+    assert got.diffuse_maps == want["diffuse_maps"]
+    for k in ("vertices", "indices", "materials", "mat_indices"):
+        assert np.array_equal(getattr(got, k).view(np.uint32), want[k].view(np.uint32)), k
+    assert list(got.materials[1]) == [0.5, 0.5, 0.5, 0, 0, 0]  # statements after a map_Kd still parse
+
+
+@pytest.mark.skipif(not HAVE_MODELS, reason="/root/reference/models only exists in the build container")
+def test_reference_models_name_no_diffuse_map(pa):
+    """None of the reference's four MTL files has a map_Kd (viking_room.png ships beside viking_room.mtl without being
+    named in it): the texture of BASELINE configs[2] is set explicitly (pt_render -tex, Renderer.setTexture)."""
+    for model in ("cornell", "plane", "teapot", "viking_room"):
+        sc = pa.load_obj(os.path.join(REFERENCE_MODELS, model + ".obj"))
+        assert set(sc.diffuse_maps) == {""}, model
+
+
 def test_loader_missing_file_and_missing_mtl(pa, tmp_path):
     with pytest.raises(pa.PathTracerError):
         pa.load_obj(str(tmp_path / "does_not_exist.obj"))
