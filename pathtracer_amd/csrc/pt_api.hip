@@ -1612,13 +1612,14 @@ extern "C" int pt_get_stats(pt_ctx *c, PtStats *out)
 	out->trav_leaf_steps = h[7];
 #ifdef PT_PATHS_TIMING
 	{
-		unsigned long long t[8] = {};
+		unsigned long long t[16] = {};
 		hipMemcpy(t, c->dStats + 8, sizeof(t), hipMemcpyDeviceToHost);
 		double sum = 0;
 		for (unsigned long long x : t) sum += (double)x;
-		static const char *names[8] = { "loop", "retire", "flush", "ring", "gen", "take", "node", "leaf" };
+		static const char *names[16] = { "loop", "retire", "flush", "ring", "gen", "take", "node", "leaf", "s:prepare", "s:entry", "s:leaf",
+			                             "s:store", "f:loads", "f:math", "f:store", "-" };
 		fprintf(stderr, "[k_paths section shares]");
-		for (int i = 0; i < 8; ++i) fprintf(stderr, " %s %.1f%%", names[i], sum > 0 ? 100.0 * (double)t[i] / sum : 0.0);
+		for (int i = 0; i < 16; ++i) fprintf(stderr, " %s %.1f%%", names[i], sum > 0 ? 100.0 * (double)t[i] / sum : 0.0);
 		fprintf(stderr, "  (%.3g wave-cycles)\n", sum);
 	}
 #endif

@@ -1547,6 +1547,34 @@ __global__ void k_entry_node(const PtNode4 *nodes, uint32_t nNodes, uint32_t roo
 		}
 		for (int a = 0; a < 3; ++a) maxAbs = fmaxf(maxAbs, fmaxf(fabsf(lo[i][a]), fabsf(hi[i][a])));
 	}
+	uint32_t nInnerKids = 0;
+	for (int i = 0; i < n; ++i) nInnerKids += (ref[i] & PT_LEAF_FLAG) ? 0u : 1u;
+	if (nInnerKids == 0 && !instanceLeaves)
+	{
+		// all leaves (k_paths' flat form): largest box first, i.e. visited LAST -- the small leaves (the things standing in a
+		// room) are tested before the large ones (its walls), which are then skipped when they lie behind what was hit
+		// (insertion sort, stable; any order gives the same image)
+		auto areaOf = [&](int i) {
+			const float dx = hi[i][0] - lo[i][0], dy = hi[i][1] - lo[i][1], dz = hi[i][2] - lo[i][2];
+			return (dx * dy + dy * dz) + dz * dx;
+		};
+		for (int i = 1; i < n; ++i)
+			for (int j = i; j > 0 && areaOf(j) > areaOf(j - 1); --j)
+			{
+				const uint32_t r = ref[j];
+				ref[j] = ref[j - 1];
+				ref[j - 1] = r;
+				for (int a = 0; a < 3; ++a)
+				{
+					float t = lo[j][a];
+					lo[j][a] = lo[j - 1][a];
+					lo[j - 1][a] = t;
+					t = hi[j][a];
+					hi[j][a] = hi[j - 1][a];
+					hi[j - 1][a] = t;
+				}
+			}
+	}
 	const float pad = maxAbs * 3.814697265625e-06f;  // 2^-18
 	float org[3] = { INFINITY, INFINITY, INFINITY };
 	for (int i = 0; i < n; ++i)

@@ -91,6 +91,18 @@ constexpr uint32_t kRefillLanesFlat = PT_REFILL_LANES;  // flat scenes (a ray ma
 // replaced sooner (viking_room +2.5 %, teapot grid +1.7 %, 2 M-triangle mesh +0.3 % against 32)
 constexpr uint32_t kRefillLanesTree = PT_REFILL_LANES_TREE;
 constexpr uint32_t kNoPath = 0xFFFFFFFFu;
+// flat scenes: a leaf the box test selected is skipped when its box begins behind what the ray has hit meanwhile
+#ifndef PT_FLAT_CULL
+#define PT_FLAT_CULL 1
+#endif
+constexpr bool kFlatCull = PT_FLAT_CULL != 0;
+#ifndef PT_RING_PREFETCH
+#define PT_RING_PREFETCH 1
+#endif
+constexpr bool kRingPrefetch = PT_RING_PREFETCH != 0;
+#ifndef PT_FLAT_LDS_QUADS
+#define PT_FLAT_LDS_QUADS 1
+#endif
 
 // A kernel argument that only a cold part of k_paths needs (camera-ray generation, the gather fallback of the shading,
 // the epilogue), read from the kernarg segment WHERE it is used: the block of arguments is ~60 SGPRs, and what the
@@ -136,7 +148,7 @@ __device__ __forceinline__ uint32_t popcWave(unsigned long long m)
 // Tuning builds only (-DPT_PATHS_TIMING): wall cycles of every section of the loop, summed per wave into a.trav[6 + section]
 // (s_memtime stamps; the stamps themselves cost ~10 % -- shares, not absolute times).
 #ifdef PT_PATHS_TIMING
-#define PT_T_SECTIONS 8
+#define PT_T_SECTIONS 16
 #define PT_T_MARK(sec)                                               \
 	{                                                                \
 		const unsigned long long now_ = __builtin_amdgcn_s_memtime(); \
@@ -156,8 +168,22 @@ enum
 	PT_T_GEN = 4,    // claims + camera rays + staging
 	PT_T_TAKE = 5,   // idle lanes pick prepared rays up
 	PT_T_NODE = 6,
-	PT_T_LEAF = 7
+	PT_T_LEAF = 7,
+	// parts of the flat staging (the time before the first of them is the wait for the ring's / the generator's data) ...
+	PT_T_S_PREPARE = 8,
+	PT_T_S_ENTRY = 9,
+	PT_T_S_LEAF = 10,
+	PT_T_S_STORE = 11,
+	// ... and of the shading pass: until its loads have arrived, arithmetic, stores
+	PT_T_F_LOADS = 12,
+	PT_T_F_MATH = 13,
+	PT_T_F_STORE = 14
 };
+#ifdef PT_PATHS_TIMING
+#define PT_T_PIN(x) asm volatile("" ::"v"(x));
+#else
+#define PT_T_PIN(x)
+#endif
 
 // kInst: two-level scene (pt_set_instances).  A lane starts in the top-level tree (inst == PT_NO_INSTANCE), where
 // a leaf reference is an instance index: the lane saves its prepared world ray in LDS, transforms the ray with the
@@ -198,6 +224,22 @@ __global__ void __launch_bounds__(PT_WAVE) PT_PATHS_OCCUPANCY k_paths(PtPathsArg
 	if (kEntry)
 	{
 		if (threadIdx.x < PT_ENTRY_REC) sEntry[threadIdx.x] = a.entry[threadIdx.x];
+		__syncthreads();
+	}
+	// flat scenes: their (at most 16) quads, one copy in x, y, z order (pt_leaf_test picks the ray's axis order by address): a
+	// leaf test waits for LDS instead of for a divergent load from memory
+	constexpr bool kLdsQuads = kFlat && PT_FLAT_LDS_QUADS;
+	__shared__ float sQuads[kLdsQuads ? PT_LDS_QUAD_WORDS : 1];
+	if (kLdsQuads)
+	{
+		const uint32_t nq = a.sc.nQuads <= PT_LDS_QUADS ? a.sc.nQuads : 0u;  // (a flat scene has at most 16 leaves)
+		const uint32_t *src = reinterpret_cast<const uint32_t *>(a.sc.quads + 2 * (size_t)a.sc.nQuads);  // plane 2: x, y, z
+		uint32_t *dst = reinterpret_cast<uint32_t *>(sQuads);
+		for (uint32_t i = threadIdx.x; i < nq * 14u; i += PT_WAVE)
+		{
+			const uint32_t q = i / 14u, w = i % 14u;
+			dst[w < 12u ? q * 12u + w : PT_LDS_QUADS * 12u + 2u * q + (w - 12u)] = src[q * 16u + w];
+		}
 		__syncthreads();
 	}
 	__shared__ uint32_t sSave[kInst ? kSaveFields : 1][PT_WAVE];
@@ -244,6 +286,20 @@ __global__ void __launch_bounds__(PT_WAVE) PT_PATHS_OCCUPANCY k_paths(PtPathsArg
 	float4 *ringO = a.ringO + (size_t)blockIdx.x * PT_PATHS_RING;
 	float4 *ringD = a.ringD + (size_t)blockIdx.x * PT_PATHS_RING;
 	uint32_t ringHead = 0, ringCount = 0;
+	// the next full batch of the ring, requested as soon as the ring holds it (end of a shading pass, or after a batch was
+	// staged) and used when the staging area next runs empty: the load's latency passes while the wave traverses
+	constexpr bool kPrefetch = kRingPrefetch && kFlat;  // (scenes with a tree: no difference measured, eight registers more)
+	float4 pfO = make_float4(0.0f, 0.0f, 0.0f, 0.0f), pfD = pfO;
+	bool pfValid = false;
+	auto prefetchRing = [&]() {
+		if (kPrefetch && !pfValid && ringCount >= PT_WAVE)
+		{
+			const uint32_t slot = (ringHead + lane) & (PT_PATHS_RING - 1);
+			pfO = ringO[slot];
+			pfD = ringD[slot];
+			pfValid = true;
+		}
+	};
 
 	uint32_t inCount = 0, inPos = 0;      // prepared rays in sIn
 	uint32_t doneHead = 0, doneCount = 0;  // LDS ring of finished rays: first entry (< kDoneRing) and entries parked
@@ -283,6 +339,7 @@ __global__ void __launch_bounds__(PT_WAVE) PT_PATHS_OCCUPANCY k_paths(PtPathsArg
 			fsc.texW = PT_COLD(sc.texW);
 			fsc.texH = PT_COLD(sc.texH);
 		}
+		PT_T_MARK(PT_T_F_LOADS)
 		if ((uint32_t)lane < count)
 		{
 			uint32_t e = pt_ring_at<kDoneRing>(doneHead + (uint32_t)lane);
@@ -307,8 +364,18 @@ __global__ void __launch_bounds__(PT_WAVE) PT_PATHS_OCCUPANCY k_paths(PtPathsArg
 				float4 T = a.state[pq];  // throughput, rng state
 				uint32_t seed = __float_as_uint(T.w);
 				float3x kd, ke;
+#ifdef PT_PATHS_TIMING
+				{
+					// (tuning build: wait for the state and for the first and last word of the shading record)
+					const float4 *r = reinterpret_cast<const float4 *>(fsc.shade + prim);
+					float4 r0 = r[0], r5 = r[5];
+					PT_T_PIN(T.w) PT_T_PIN(r0.x) PT_T_PIN(r5.w) PT_T_PIN(u)
+					PT_T_MARK(PT_T_F_MATH)
+				}
+#endif
 				pt_shade_hit<true>(fsc, prim, u, v, seed, no, nd, kd, ke,
 				             kInst ? a.instances + 24 * (size_t)sDone[kDoneFields][e] : nullptr);
+				PT_T_PIN(nd.x) PT_T_PIN(nd.z)
 				float ex = ke.x, ey = ke.y, ez = ke.z;
 				if (ex != 0.0f || ey != 0.0f || ez != 0.0f)
 				{
@@ -325,6 +392,7 @@ __global__ void __launch_bounds__(PT_WAVE) PT_PATHS_OCCUPANCY k_paths(PtPathsArg
 				if (kStats) ++nHits;
 			}
 		}
+		PT_T_MARK(PT_T_F_STORE)
 		doneHead = pt_ring_at<kDoneRing>(doneHead + count);
 		doneCount -= count;
 		unsigned long long am = __ballot(alive);
@@ -335,6 +403,7 @@ __global__ void __launch_bounds__(PT_WAVE) PT_PATHS_OCCUPANCY k_paths(PtPathsArg
 			ringD[slot] = make_float4(nd.x, nd.y, nd.z, __uint_as_float(pq));
 		}
 		ringCount += popcWave(am);
+		prefetchRing();
 	};
 
 	// Prepares the rays of a staging batch (lanes with `valid`; every lane of the wave calls) and writes them into the
@@ -387,18 +456,33 @@ __global__ void __launch_bounds__(PT_WAVE) PT_PATHS_OCCUPANCY k_paths(PtPathsArg
 		PtLaneRay pr = {};
 		PtBest b = { tmax, PT_NO_HIT, 0.0f, 0.0f, 1.0f };
 		uint32_t m = 0;
+		PT_T_PIN(o.x) PT_T_PIN(d.x) PT_T_MARK(PT_T_S_PREPARE)
 		if (valid)
 		{
 			pr = pt_prepare_ray<true>(o, d);
+#ifdef PT_PROBE_VALU
+			{
+				// tuning probe: PT_PROBE_VALU independent vector instructions that do nothing
+				float x0 = pr.ox, x1 = pr.oy, x2 = pr.oz, x3 = pr.ix;
+#pragma unroll
+				for (int i = 0; i < PT_PROBE_VALU / 4; ++i)
+					asm volatile("v_fma_f32 %0, %0, %0, %0\n\tv_fma_f32 %1, %1, %1, %1\n\tv_fma_f32 %2, %2, %2, %2\n\tv_fma_f32 %3, %3, %3, %3"
+					             : "+v"(x0), "+v"(x1), "+v"(x2), "+v"(x3));
+			}
+#endif
+			PT_T_PIN(pr.Sx) PT_T_PIN(pr.ix) PT_T_MARK(PT_T_S_ENTRY)
 			m = pt_entry_test(sEntry, pr, tmin, tmax);
+			PT_T_PIN(m) PT_T_MARK(PT_T_S_LEAF)
 			if (kStats) ++nodeFetches;
 			if (m)
 			{
 				const uint32_t ref = pt_entry_next(sEntry, m);
 				if (kStats) ++leafVisits;
-				pt_leaf_test<true>(sc, pr, tmin, b, ref, triTests);
+				pt_leaf_test<true, kLdsQuads>(sc, pr, tmin, b, ref, triTests, 0u, nullptr, sQuads);
 			}
+			PT_T_PIN(b.t) PT_T_PIN(b.prim)
 		}
+		PT_T_MARK(PT_T_S_STORE)
 		const bool more = valid && m != 0u, parked = valid && m == 0u && b.prim != PT_NO_HIT;
 		const unsigned long long mm = __ballot(more), hm = __ballot(parked);
 		if (parked)
@@ -418,6 +502,12 @@ __global__ void __launch_bounds__(PT_WAVE) PT_PATHS_OCCUPANCY k_paths(PtPathsArg
 			sIn[0][r] = __float_as_uint(pr.ox);
 			sIn[1][r] = __float_as_uint(pr.oy);
 			sIn[2][r] = __float_as_uint(pr.oz);
+			if (kFlatCull)
+			{
+				sIn[3][r] = __float_as_uint(pr.ix);
+				sIn[4][r] = __float_as_uint(pr.iy);
+				sIn[5][r] = __float_as_uint(pr.iz);
+			}
 			sIn[6][r] = __float_as_uint(pr.Sx);
 			sIn[7][r] = __float_as_uint(pr.Sy);
 			sIn[8][r] = __float_as_uint(pr.Sz);
@@ -501,7 +591,13 @@ __global__ void __launch_bounds__(PT_WAVE) PT_PATHS_OCCUPANCY k_paths(PtPathsArg
 						n = ringCount < PT_WAVE ? ringCount : PT_WAVE;
 						__syncthreads();  // staging contents consumed; ring stores of earlier flushes complete
 						float4 ro = make_float4(0.0f, 0.0f, 0.0f, 0.0f), rd = ro;
-						if ((uint32_t)lane < n)
+						if (kPrefetch && pfValid)
+						{
+							ro = pfO;
+							rd = pfD;
+							pfValid = false;
+						}
+						else if ((uint32_t)lane < n)
 						{
 							uint32_t slot = (ringHead + lane) & (PT_PATHS_RING - 1);
 							ro = ringO[slot];
@@ -511,6 +607,7 @@ __global__ void __launch_bounds__(PT_WAVE) PT_PATHS_OCCUPANCY k_paths(PtPathsArg
 						               __float_as_uint(rd.w));
 						ringHead += n;
 						ringCount -= n;
+						prefetchRing();
 					}
 					else if (!genDone)
 					{
@@ -708,13 +805,31 @@ __global__ void __launch_bounds__(PT_WAVE) PT_PATHS_OCCUPANCY k_paths(PtPathsArg
 		{
 			// every lane that holds a ray is at a leaf: test it, then on to the next leaf the ray's box test selected
 			PT_T_MARK(PT_T_LEAF)
-			const PtLaneRay fray = { ox, oy, oz, 0.0f, 0.0f, 0.0f, Sx, Sy, Sz, kpack };
+			const PtLaneRay fray = { ox, oy, oz, ix, iy, iz, Sx, Sy, Sz, kpack };
 			if (kStats) ++leafSteps;
 			if (cur != PT_TRAVERSAL_DONE)
 			{
 				if (kStats) ++leafVisits;
-				pt_leaf_test<true>(sc, fray, tmin, best, cur, triTests);
-				cur = pend ? pt_entry_next(sEntry, pend) : PT_TRAVERSAL_DONE;
+				pt_leaf_test<true, kLdsQuads>(sc, fray, tmin, best, cur, triTests, 0u, nullptr, sQuads);
+				if (kFlatCull)
+				{
+					// the other leaves the box test selected were selected against tmax: once something is hit, one whose box
+					// begins behind that hit is skipped (the node step's test, t0 <= t * 1.000001f, with its near planes only)
+					cur = PT_TRAVERSAL_DONE;
+					const float limit = best.t * 1.000001f;
+					while (pend)
+					{
+						const uint32_t bit = (uint32_t)__builtin_ctz(pend);
+						pend &= pend - 1u;
+						const uint32_t child = (uint32_t)(PT_ENTRY_WIDTH - 1) - bit;
+						if (best.prim == PT_NO_HIT || pt_entry_child_t0(sEntry, child, fray, tmin) <= limit)
+						{
+							cur = reinterpret_cast<const uint32_t *>(sEntry + 2)[child];
+							break;
+						}
+					}
+				}
+				else cur = pend ? pt_entry_next(sEntry, pend) : PT_TRAVERSAL_DONE;
 			}
 			continue;
 		}

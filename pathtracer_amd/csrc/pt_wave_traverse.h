@@ -281,6 +281,14 @@ __device__ __forceinline__ uint32_t pt_entry_test(const uint4 *e, const PtLaneRa
 	const float bx = (h0.x - ray.ox) * ray.ix, by = (h0.y - ray.oy) * ray.iy, bz = (h0.z - ray.oz) * ray.iz;
 	const float4 *planes = rec + 2 + G;
 	const int nx = negx ? 3 * G : 0, ny = negy ? 3 * G : 0, nz = negz ? 3 * G : 0;
+	// The 1e-6 slack of the far side (node step: t0 <= t1 * 1.000001f) is folded into the far planes' coefficients -- the
+	// factor is positive, so it commutes with the min up to one rounding per operand, which the slack itself (8 ulp) and the
+	// padding of the boxes cover -- one multiplication per child less.  Without the nearest key the outcome goes into the
+	// set as the sign bit of t1 - t0 (set: missed; neither operand is a NaN, they are never infinities of the same sign, and
+	// equal operands give +0), one v_alignbit per child instead of a compare and a two-instruction insert.
+	const float slack = 1.000001f;
+	const float axf = ax * slack, ayf = ay * slack, azf = az * slack;
+	const float bxf = bx * slack, byf = by * slack, bzf = bz * slack, tmaxf = tmax * slack;
 	uint32_t mask = 0, nearest = 0xFFFFFFFFu;
 #pragma unroll
 	for (int g = 0; g < G; ++g)
@@ -300,13 +308,18 @@ __device__ __forceinline__ uint32_t pt_entry_test(const uint4 *e, const PtLaneRa
 			float tnx = __builtin_fmaf(vnx[c], ax, bx);
 			float tny = __builtin_fmaf(vny[c], ay, by);
 			float tnz = __builtin_fmaf(vnz[c], az, bz);
-			float tfx = __builtin_fmaf(vfx[c], ax, bx);
-			float tfy = __builtin_fmaf(vfy[c], ay, by);
-			float tfz = __builtin_fmaf(vfz[c], az, bz);
+			float tfx = __builtin_fmaf(vfx[c], axf, bxf);
+			float tfy = __builtin_fmaf(vfy[c], ayf, byf);
+			float tfz = __builtin_fmaf(vfz[c], azf, bzf);
 			float t0 = fmaxf(fmaxf(tnx, tny), fmaxf(tnz, tmin));
-			float t1 = fminf(fminf(tfx, tfy), fminf(tfz, tmax));
-			const bool hit = t0 <= t1 * 1.000001f;  // same test as a node step; an empty slot fails it whatever the ray
-			mask = (mask + mask) + (hit ? 1u : 0u);  // one add-with-carry per child
+			float t1 = fminf(fminf(tfx, tfy), fminf(tfz, tmaxf));
+			if (!kNearest)
+			{
+				mask = __builtin_amdgcn_alignbit(mask, __float_as_uint(t1 - t0), 31);  // (mask << 1) | missed
+				continue;
+			}
+			const bool hit = t0 <= t1;  // the node step's test (slack folded in above); an empty slot fails it whatever the ray
+			mask = (mask + mask) + (hit ? 1u : 0u);
 			if (kNearest)
 			{
 				// entry distances are >= tmin >= 0, so their bit patterns order like unsigned integers; the low four bits
@@ -316,6 +329,7 @@ __device__ __forceinline__ uint32_t pt_entry_test(const uint4 *e, const PtLaneRa
 			}
 		}
 	}
+	if (!kNearest) mask = ~mask & ((1u << W) - 1u);
 	static_assert(!kNearest || W <= 16, "four bits for the nearest child");
 	return kNearest ? (mask | ((nearest & 15u) << 16)) : mask;
 }
@@ -327,6 +341,20 @@ __device__ __forceinline__ uint32_t pt_entry_first(const uint4 *e, uint32_t m, u
 	const uint32_t bit = (m >> 16) & 15u;
 	pend = (m & 0xFFFFu) & ~(1u << bit);
 	return reinterpret_cast<const uint32_t *>(e + 2)[(uint32_t)(PT_ENTRY_WIDTH - 1) - bit];
+}
+
+// Entry distance of `ray` into child `child` of the entry node: the near-plane half of pt_entry_test, same arithmetic.
+__device__ __forceinline__ float pt_entry_child_t0(const uint4 *e, uint32_t child, const PtLaneRay &ray, float tmin)
+{
+	constexpr uint32_t W = PT_ENTRY_WIDTH, G = W / 4;
+	const float4 h0 = reinterpret_cast<const float4 *>(e)[0];
+	const float *planes = reinterpret_cast<const float *>(e + 2 + G);
+	const float bx = (h0.x - ray.ox) * ray.ix, by = (h0.y - ray.oy) * ray.iy, bz = (h0.z - ray.oz) * ray.iz;
+	const float vnx = planes[((ray.kpack & 64u) ? 3u * W : 0u) + child];
+	const float vny = planes[((ray.kpack & 128u) ? 4u * W : W) + child];
+	const float vnz = planes[((ray.kpack & 256u) ? 5u * W : 2u * W) + child];
+	const float tnx = __builtin_fmaf(vnx, ray.ix, bx), tny = __builtin_fmaf(vny, ray.iy, by), tnz = __builtin_fmaf(vnz, ray.iz, bz);
+	return fmaxf(fmaxf(tnx, tny), fmaxf(tnz, tmin));
 }
 
 // The reference of the next child in `pend` (not zero), which it removes from the set.
@@ -360,10 +388,15 @@ __device__ __forceinline__ void pt_stack_push(uint32_t v, int &sp, uint32_t (*sS
 // go to the lower instance index, then the lower primitive id).  Single-level callers pass 0 and a dummy.
 // kQuads: the tree may hold quad leaf references (PtQuad64; k_paths on scenes made of quad faces).
 // The triangles (or the quad) of leaf reference `cur` against the ray: the leaf step without its stack pop.
-template <bool kQuads = false>
+// ldsQuads (kLdsQuads): the scene's quads in LDS, PT_LDS_QUADS records of twelve floats (v0 .. v3 in x, y, z order) followed by
+// their primitive id pairs -- ONE copy, not three rotated ones: the lane picks the components in its ray's axis order by
+// address, so the values are the ones the rotated records in memory hold.
+#define PT_LDS_QUADS 16u
+#define PT_LDS_QUAD_WORDS (PT_LDS_QUADS * 14u)
+template <bool kQuads = false, bool kLdsQuads = false>
 __device__ __forceinline__ void pt_leaf_test(const PtSceneDev &sc, const PtLaneRay &ray, float tmin, PtBest &best,
                                              const uint32_t cur, uint32_t &triTests, uint32_t curInst = 0u,
-                                             uint32_t *bestInst = nullptr)
+                                             uint32_t *bestInst = nullptr, const float *ldsQuads = nullptr)
 {
 	const float ox = ray.ox, oy = ray.oy, oz = ray.oz, Sx = ray.Sx, Sy = ray.Sy, Sz = ray.Sz;
 	const uint32_t kpack = ray.kpack;
@@ -439,9 +472,25 @@ __device__ __forceinline__ void pt_leaf_test(const PtSceneDev &sc, const PtLaneR
 		{
 			// quad leaf: triangle A = (v0, v1, v2), triangle B = (v0, v2, v3); four vertices sheared once
 			triTests += 2u;
-			const float4 *qp = reinterpret_cast<const float4 *>(sc.quads + (size_t)kz * sc.nQuads + first);
-			const float4 a = qp[0], b = qp[1], c = qp[2];
-			const uint2 prims = *reinterpret_cast<const uint2 *>(qp + 3);
+			float4 a, b, c;
+			uint2 prims;
+			if (kLdsQuads)
+			{
+				const uint32_t kx = kz == 2u ? 0u : kz + 1u, ky = kz == 0u ? 2u : kz - 1u;
+				const float *qx = ldsQuads + first * 12u + kx, *qy = ldsQuads + first * 12u + ky, *qz = ldsQuads + first * 12u + kz;
+				a = make_float4(qx[0], qy[0], qz[0], qx[3]);
+				b = make_float4(qy[3], qz[3], qx[6], qy[6]);
+				c = make_float4(qz[6], qx[9], qy[9], qz[9]);
+				prims = reinterpret_cast<const uint2 *>(ldsQuads + PT_LDS_QUADS * 12u)[first];
+			}
+			else
+			{
+				const float4 *qp = reinterpret_cast<const float4 *>(sc.quads + (size_t)kz * sc.nQuads + first);
+				a = qp[0];
+				b = qp[1];
+				c = qp[2];
+				prims = *reinterpret_cast<const uint2 *>(qp + 3);
+			}
 			float P0x = a.x - rox, P0y = a.y - roy, P0z = a.z - roz;
 			float P1x = a.w - rox, P1y = b.x - roy, P1z = b.y - roz;
 			float P2x = b.z - rox, P2y = b.w - roy, P2z = c.x - roz;

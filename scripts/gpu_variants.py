@@ -21,6 +21,10 @@ print("%%-28s frame %%.3f ms  %%.0f Mrays/s   nodes/ray %%.3f tris/ray %%.3f" %%
 for rnd in range(2):
     for v in variants:
         env = dict(os.environ)
+        v, *sets = v.split("@")  # name@VAR=value@VAR2=value: environment for this variant only
+        for kv in sets:
+            k, _, val = kv.partition("=")
+            env[k] = val
         if v != "default":
             env["PT_HIP_LIB"] = os.path.abspath(os.path.join(root, "pathtracer_amd", "variants", f"libpt_hip_{v}.so"))
         subprocess.run([sys.executable, "-c", code], env=env, check=True)
