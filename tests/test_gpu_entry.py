@@ -220,3 +220,42 @@ def test_rays_along_shared_edges_do_not_leak(rt, pa, O):
         hits = rt.debugPrimaryHits()
         assert np.array_equal(hits["prim"], ohits["prim"]) and np.array_equal(bits(hits["t"]), bits(ohits["t"]))
     rt.setPipeline(PT_PIPELINE_PERSISTENT)
+
+
+def test_flat_scene_skips_leaves_behind_the_hit(rt, pa, O):
+    """Flat form with something to skip: 14 parallel quads one behind the other, of growing size (the builder orders the
+    entry node's leaves by box area, so the small near ones are tested first), two of them coincident (equal t: the lower
+    primitive id wins, so a leaf that begins exactly AT the hit must still be tested), one emissive; a leaf whose box begins
+    behind the ray's hit is not tested.  Image and ray count equal the oracle's; fewer than two quad tests per ray although a
+    ray through the middle crosses all 14 boxes."""
+    from pathtracer_amd.api import PT_ACCEL_BVH4_PLOC, PT_PROFILE_TRAVERSAL
+    quads = []
+    for i in range(14):
+        z = -0.25 * (i if i != 9 else 8)  # quads 8 and 9 coincide
+        h = 0.2 + 0.12 * i
+        quads.append([[-h, -h, z], [h, -h, z], [h, h, z], [-h, h, z]])
+    t = []
+    for q in quads:
+        t += [[q[0], q[1], q[2]], [q[0], q[2], q[3]]]
+    t = np.array(t, dtype=np.float32)
+    nt = t.shape[0]
+    verts = np.zeros((3 * nt, 11), dtype=np.float32)
+    verts[:, 0:3] = t.reshape(-1, 3)
+    verts[:, 5] = 1.0
+    verts[:, 6:9] = 1.0
+    mats = np.array([[0.7, 0.6, 0.5, 0, 0, 0], [0, 0, 0, 5, 6, 7]], dtype=np.float32)
+    mid = np.zeros(nt, dtype=np.uint32)
+    mid[2 * 13:] = 1  # the largest, farthest quad is the light
+    sc = pa.Scene(verts, np.arange(3 * nt, dtype=np.uint32), mats, mid)
+    osc = O.OracleScene(sc.vertices, sc.indices, sc.materials, sc.mat_indices)
+    W, H = 96, 72
+    view = pa.look_at((0.3, 0.2, 2.0), (0.0, 0.0, -1.0), (0, 1, 0))
+    proj = pa.perspective(np.radians(50.0), W / H, 0.1, 100.0)
+    proj[5] *= -1
+    want, rays = osc.render(view, proj, W, H, frames=2, spp_per_frame=3, max_depth=6, seed=11)
+    res = _render(rt, pa, sc, view, proj, W, H, PT_ACCEL_BVH4_PLOC)
+    for prof, (img, st) in res.items():
+        assert st.rays_total == rays and np.array_equal(bits(img), bits(want)), prof
+    st = res[PT_PROFILE_TRAVERSAL][1]
+    assert st.trav_nodes == st.rays_total and st.quad_leaves >= 12  # flat form; (the coincident pair may be paired crosswise)
+    assert st.trav_tris / st.rays_total < 4.0, st.trav_tris / st.rays_total
