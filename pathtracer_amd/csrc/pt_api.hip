@@ -1074,6 +1074,10 @@ int ensureLcgSkip(pt_ctx *c)
 int ensurePersistent(pt_ctx *c, size_t records, bool *outOfMemory)
 {
 	*outOfMemory = false;
+	// (the flat-scene kernel keeps the survivors' throughput and RNG state in the first waves * PT_PATHS_RING records of the
+	// state buffer: a third ring array, pt_paths.hip)
+	const size_t ringRecords = (size_t)c->cfg.bounceWaves * PT_PATHS_RING;
+	if (records < ringRecords) records = ringRecords;
 	if (records > c->pCap)
 	{
 		PT_HIP(c, hipStreamSynchronize(c->stream));

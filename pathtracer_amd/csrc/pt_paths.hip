@@ -103,6 +103,11 @@ constexpr bool kFlatCull = PT_FLAT_CULL != 0;
 #define PT_RING_LIFO 1
 #endif
 constexpr bool kRingLifoOn = PT_RING_LIFO != 0;
+// flat scenes: throughput and RNG state travel with the ray (third ring record, four more staging and done rows) instead of
+// living in a per-path table in memory that the shading pass has to gather from
+#ifndef PT_FLAT_CARRY_STATE
+#define PT_FLAT_CARRY_STATE 1
+#endif
 #ifndef PT_RING_PREFETCH
 #define PT_RING_PREFETCH 1
 #endif
@@ -225,8 +230,17 @@ __global__ void __launch_bounds__(PT_WAVE) PT_PATHS_OCCUPANCY k_paths(PtPathsArg
 	constexpr int kInDir = kInFields + (kEntry ? 1 : 0);  // first row of the world direction (kInst)
 	constexpr int kInBest = kInFields + 1;  // kFlat: best hit so far (t, prim, V, W, det) of a ray that was tested while staged
 	__shared__ uint32_t sStack[kFlat ? 1 : kStackLds][PT_WAVE];
-	__shared__ uint32_t sIn[kInFields + (kInst ? 3 : 0) + (kEntry ? 1 : 0) + (kFlat ? 5 : 0)][PT_WAVE];
-	__shared__ uint32_t sDone[kDoneFields + (kInst ? 1 : 0)][kDoneRing];
+	// kCarry (flat scenes): throughput and RNG state travel with the ray.  To stay within 10 240 B of LDS the rows are packed
+	// -- a flat scene has at most 16 leaves of at most 8 triangles, so a primitive id is a byte (0xFF: none): it shares the word
+	// of the axis bits and the depth (staging row 9: kz | signs | depth << 16 | primitive << 24; done row 3: primitive | depth
+	// << 8, done row 5 is free for the state) -- and the staging area holds 48 rays instead of 64 (a batch that hands more than
+	// that to the lanes tests another leaf first: stage()).
+	constexpr bool kCarry = kFlat && PT_FLAT_CARRY_STATE;
+	constexpr int kInCap = kCarry ? 48 : PT_WAVE;                    // rays the staging area holds
+	constexpr int kInState = kInBest + 4;                           // kCarry: throughput x, y, z and RNG state (best hit: t V W det)
+	constexpr int kDoneState = 5;                                   // kCarry: the same of a parked hit, rows 5 .. 8
+	__shared__ uint32_t sIn[kInFields + (kInst ? 3 : 0) + (kEntry ? 1 : 0) + (kFlat ? (kCarry ? 8 : 5) : 0)][kInCap];
+	__shared__ uint32_t sDone[kDoneFields + (kInst ? 1 : 0) + (kCarry ? 3 : 0)][kDoneRing];
 	__shared__ uint4 sEntry[kEntry ? PT_ENTRY_REC : 1];
 	if (kEntry)
 	{
@@ -292,12 +306,15 @@ __global__ void __launch_bounds__(PT_WAVE) PT_PATHS_OCCUPANCY k_paths(PtPathsArg
 	// ---- wave-private survivor ring in global memory ----
 	float4 *ringO = a.ringO + (size_t)blockIdx.x * PT_PATHS_RING;
 	float4 *ringD = a.ringD + (size_t)blockIdx.x * PT_PATHS_RING;
+	float4 *ringT = a.state + (size_t)blockIdx.x * PT_PATHS_RING;  // kCarry: (throughput, RNG state) of the survivors; the table is not used
 	uint32_t ringHead = 0, ringCount = 0;
+	float cTx = 1.0f, cTy = 1.0f, cTz = 1.0f;  // kCarry: throughput and RNG state of the lane's ray
+	uint32_t cSeed = 0;
 	// the next full batch of the ring, requested as soon as the ring holds it (end of a shading pass, or after a batch was
 	// staged) and used when the staging area next runs empty: the load's latency passes while the wave traverses
 	constexpr bool kRingLifo = kRingLifoOn && kFlat;
-	constexpr bool kPrefetch = kRingPrefetch && kFlat;  // (scenes with a tree: no difference measured, eight registers more)
-	float4 pfO = make_float4(0.0f, 0.0f, 0.0f, 0.0f), pfD = pfO;
+	constexpr bool kPrefetch = kRingPrefetch && kFlat && !(kFlat && PT_FLAT_CARRY_STATE);  // (carried state: no registers left for it)  // (scenes with a tree: no difference measured, eight registers more)
+	float4 pfO = make_float4(0.0f, 0.0f, 0.0f, 0.0f), pfD = pfO, pfT = pfO;
 	bool pfValid = false;
 	auto prefetchRing = [&]() {
 		if (kPrefetch && !pfValid && ringCount >= PT_WAVE)
@@ -305,6 +322,7 @@ __global__ void __launch_bounds__(PT_WAVE) PT_PATHS_OCCUPANCY k_paths(PtPathsArg
 			const uint32_t slot = kRingLifo ? ringCount - PT_WAVE + lane : (ringHead + lane) & (PT_PATHS_RING - 1);
 			pfO = ringO[slot];
 			pfD = ringD[slot];
+			if (kCarry) pfT = ringT[slot];
 			pfValid = true;
 			if (kRingLifo) ringCount -= PT_WAVE;  // taken off the stack now: a later shading pass pushes on top of what is left
 		}
@@ -332,6 +350,7 @@ __global__ void __launch_bounds__(PT_WAVE) PT_PATHS_OCCUPANCY k_paths(PtPathsArg
 	// Shades `count` (<= 64) parked hits and sends the survivors to the wave's ring.
 	auto flush = [&](uint32_t count) {
 		bool alive = false;
+		float4 nT = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
 		float3x no = { 0, 0, 0 }, nd = { 0, 0, 0 };
 		uint32_t pq = 0, depth = 0;
 		const int maxDepth = PT_COLD(maxDepth);
@@ -354,7 +373,12 @@ __global__ void __launch_bounds__(PT_WAVE) PT_PATHS_OCCUPANCY k_paths(PtPathsArg
 			uint32_t e = pt_ring_at<kDoneRing>(doneHead + (uint32_t)lane);
 			uint32_t prim = sDone[3][e];
 			pq = sDone[4][e];
-			depth = sDone[5][e] >> 16;
+			if (kCarry)
+			{
+				depth = prim >> 8;
+				prim &= 0xFFu;
+			}
+			else depth = sDone[5][e] >> 16;
 			if (prim != PT_NO_HIT)  // rmiss: hitValue = 0, emission = 0, terminate -> nothing to do
 			{
 				float V = __uint_as_float(sDone[0][e]), W = __uint_as_float(sDone[1][e]), det = __uint_as_float(sDone[2][e]);
@@ -370,7 +394,11 @@ __global__ void __launch_bounds__(PT_WAVE) PT_PATHS_OCCUPANCY k_paths(PtPathsArg
 					u = V / det;
 					v = W / det;
 				}
-				float4 T = a.state[pq];  // throughput, rng state
+				float4 T;  // throughput, rng state
+				if (kCarry)
+					T = make_float4(__uint_as_float(sDone[kDoneState + 0][e]), __uint_as_float(sDone[kDoneState + 1][e]),
+					                __uint_as_float(sDone[kDoneState + 2][e]), __uint_as_float(sDone[kDoneState + 3][e]));
+				else T = a.state[pq];
 				uint32_t seed = __float_as_uint(T.w);
 				float3x kd, ke;
 #ifdef PT_PATHS_TIMING
@@ -397,7 +425,10 @@ __global__ void __launch_bounds__(PT_WAVE) PT_PATHS_OCCUPANCY k_paths(PtPathsArg
 				}
 				alive = (int)(depth + 1) < maxDepth && !((ex + ey) + ez > 0.0f);  // rgen:61 loop bound, rchit:56-58
 				if (alive)  // curAttenuation *= hitValue (rgen:79)
-					a.state[pq] = make_float4(T.x * kd.x, T.y * kd.y, T.z * kd.z, __uint_as_float(seed));
+				{
+					nT = make_float4(T.x * kd.x, T.y * kd.y, T.z * kd.z, __uint_as_float(seed));
+					if (!kCarry) a.state[pq] = nT;
+				}
 				if (kStats) ++nHits;
 			}
 		}
@@ -411,6 +442,7 @@ __global__ void __launch_bounds__(PT_WAVE) PT_PATHS_OCCUPANCY k_paths(PtPathsArg
 			                          : (ringHead + ringCount + popc64(am & lanesBelow)) & (PT_PATHS_RING - 1);
 			ringO[slot] = make_float4(no.x, no.y, no.z, __uint_as_float(depth + 1));
 			ringD[slot] = make_float4(nd.x, nd.y, nd.z, __uint_as_float(pq));
+			if (kCarry) ringT[slot] = nT;
 		}
 		ringCount += popcWave(am);
 		prefetchRing();
@@ -418,7 +450,7 @@ __global__ void __launch_bounds__(PT_WAVE) PT_PATHS_OCCUPANCY k_paths(PtPathsArg
 
 	// Prepares the rays of a staging batch (lanes with `valid`; every lane of the wave calls) and writes them into the
 	// staging area; returns how many rays wait there for a lane.
-	auto stage = [&](bool valid, float3x o, float3x d, uint32_t depth, uint32_t pq) -> uint32_t {
+	auto stage = [&](bool valid, float3x o, float3x d, uint32_t depth, uint32_t pq, float4 st) -> uint32_t {
 		if (!kFlat)
 		{
 			// With an entry node a ray whose box test selects no child has missed the scene: it is finished here (rmiss adds
@@ -493,6 +525,35 @@ __global__ void __launch_bounds__(PT_WAVE) PT_PATHS_OCCUPANCY k_paths(PtPathsArg
 			PT_T_PIN(b.t) PT_T_PIN(b.prim)
 		}
 		PT_T_MARK(PT_T_S_STORE)
+		if (kInCap < PT_WAVE)
+		{
+			// the staging area is shorter than a batch: while more rays than it holds have candidates left, every one of them
+			// tests its next leaf here (skipping those behind its hit, as a lane would)
+			while (popcWave(__ballot(valid && m != 0u)) > (uint32_t)kInCap)
+			{
+				uint32_t ref = PT_TRAVERSAL_DONE;
+				if (valid)
+				{
+					const float limit = b.t * 1.000001f;
+					while (m)
+					{
+						const uint32_t bit = (uint32_t)__builtin_ctz(m);
+						m &= m - 1u;
+						const uint32_t child = (uint32_t)(PT_ENTRY_WIDTH - 1) - bit;
+						if (!kFlatCull || b.prim == PT_NO_HIT || pt_entry_child_t0(sEntry, child, pr, tmin) <= limit)
+						{
+							ref = reinterpret_cast<const uint32_t *>(sEntry + 2)[child];
+							break;
+						}
+					}
+				}
+				if (ref != PT_TRAVERSAL_DONE)
+				{
+					if (kStats) ++leafVisits;
+					pt_leaf_test<true, kLdsQuads>(sc, pr, tmin, b, ref, triTests, 0u, nullptr, sQuads);
+				}
+			}
+		}
 		const bool more = valid && m != 0u, parked = valid && m == 0u && b.prim != PT_NO_HIT;
 		const unsigned long long mm = __ballot(more), hm = __ballot(parked);
 		if (parked)
@@ -501,9 +562,16 @@ __global__ void __launch_bounds__(PT_WAVE) PT_PATHS_OCCUPANCY k_paths(PtPathsArg
 			sDone[0][e] = __float_as_uint(b.V);
 			sDone[1][e] = __float_as_uint(b.W);
 			sDone[2][e] = __float_as_uint(b.det);
-			sDone[3][e] = b.prim;
+			sDone[3][e] = kCarry ? (b.prim | (depth << 8)) : b.prim;
 			sDone[4][e] = pq;
-			sDone[5][e] = pr.kpack | (depth << 16);
+			if (!kCarry) sDone[5][e] = pr.kpack | (depth << 16);
+			if (kCarry)
+			{
+				sDone[kDoneState + 0][e] = __float_as_uint(st.x);
+				sDone[kDoneState + 1][e] = __float_as_uint(st.y);
+				sDone[kDoneState + 2][e] = __float_as_uint(st.z);
+				sDone[kDoneState + 3][e] = __float_as_uint(st.w);
+			}
 		}
 		doneCount += popcWave(hm);  // <= 63 before (the caller shades as soon as 64 are parked), so <= 127 now
 		if (more)
@@ -521,14 +589,21 @@ __global__ void __launch_bounds__(PT_WAVE) PT_PATHS_OCCUPANCY k_paths(PtPathsArg
 			sIn[6][r] = __float_as_uint(pr.Sx);
 			sIn[7][r] = __float_as_uint(pr.Sy);
 			sIn[8][r] = __float_as_uint(pr.Sz);
-			sIn[9][r] = pr.kpack | (depth << 16);
+			sIn[9][r] = pr.kpack | (depth << 16) | (kCarry ? (b.prim == PT_NO_HIT ? 0xFFu : b.prim) << 24 : 0u);
 			sIn[10][r] = pq;
 			sIn[kInEntry][r] = m;
 			sIn[kInBest + 0][r] = __float_as_uint(b.t);
-			sIn[kInBest + 1][r] = b.prim;
-			sIn[kInBest + 2][r] = __float_as_uint(b.V);
-			sIn[kInBest + 3][r] = __float_as_uint(b.W);
-			sIn[kInBest + 4][r] = __float_as_uint(b.det);
+			if (!kCarry) sIn[kInBest + 1][r] = b.prim;
+			sIn[kInBest + (kCarry ? 1 : 2)][r] = __float_as_uint(b.V);
+			sIn[kInBest + (kCarry ? 2 : 3)][r] = __float_as_uint(b.W);
+			sIn[kInBest + (kCarry ? 3 : 4)][r] = __float_as_uint(b.det);
+			if (kCarry)
+			{
+				sIn[kInState + 0][r] = __float_as_uint(st.x);
+				sIn[kInState + 1][r] = __float_as_uint(st.y);
+				sIn[kInState + 2][r] = __float_as_uint(st.z);
+				sIn[kInState + 3][r] = __float_as_uint(st.w);
+			}
 		}
 		return popcWave(mm);
 	};
@@ -571,10 +646,17 @@ __global__ void __launch_bounds__(PT_WAVE) PT_PATHS_OCCUPANCY k_paths(PtPathsArg
 					sDone[0][e] = __float_as_uint(best.V);
 					sDone[1][e] = __float_as_uint(best.W);
 					sDone[2][e] = __float_as_uint(best.det);
-					sDone[3][e] = best.prim;
+					sDone[3][e] = kCarry ? (best.prim | ((kpack >> 16) << 8)) : best.prim;
 					sDone[4][e] = q;
-					sDone[5][e] = kpack;
+					if (!kCarry) sDone[5][e] = kpack;
 					if (kInst) sDone[kDoneFields][e] = bestInst;
+					if (kCarry)
+					{
+						sDone[kDoneState + 0][e] = __float_as_uint(cTx);
+						sDone[kDoneState + 1][e] = __float_as_uint(cTy);
+						sDone[kDoneState + 2][e] = __float_as_uint(cTz);
+						sDone[kDoneState + 3][e] = cSeed;
+					}
 					q = kNoPath;
 				}
 				doneCount += popcWave(fm);
@@ -601,11 +683,12 @@ __global__ void __launch_bounds__(PT_WAVE) PT_PATHS_OCCUPANCY k_paths(PtPathsArg
 						const bool fromRegs = kPrefetch && pfValid;
 						n = fromRegs ? PT_WAVE : (ringCount < PT_WAVE ? ringCount : PT_WAVE);
 						__syncthreads();  // staging contents consumed; ring stores of earlier flushes complete
-						float4 ro = make_float4(0.0f, 0.0f, 0.0f, 0.0f), rd = ro;
+						float4 ro = make_float4(0.0f, 0.0f, 0.0f, 0.0f), rd = ro, rt = ro;
 						if (fromRegs)
 						{
 							ro = pfO;
 							rd = pfD;
+							rt = pfT;
 							pfValid = false;
 						}
 						else if ((uint32_t)lane < n)
@@ -613,9 +696,10 @@ __global__ void __launch_bounds__(PT_WAVE) PT_PATHS_OCCUPANCY k_paths(PtPathsArg
 							uint32_t slot = kRingLifo ? ringCount - n + lane : (ringHead + lane) & (PT_PATHS_RING - 1);
 							ro = ringO[slot];
 							rd = ringD[slot];
+							if (kCarry) rt = ringT[slot];
 						}
 						staged = stage((uint32_t)lane < n, { ro.x, ro.y, ro.z }, { rd.x, rd.y, rd.z }, __float_as_uint(ro.w),
-						               __float_as_uint(rd.w));
+						               __float_as_uint(rd.w), rt);
 						if (!(kRingLifo && fromRegs))
 						{
 							ringHead += n;
@@ -685,6 +769,7 @@ __global__ void __launch_bounds__(PT_WAVE) PT_PATHS_OCCUPANCY k_paths(PtPathsArg
 						n = popcWave(__ballot(genValid));  // valid lanes are 0 .. n-1 (only the last group is partial)
 						__syncthreads();
 						float3x go = { 0, 0, 0 }, gd = { 0, 0, 1 };
+						float4 gst = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
 						uint32_t gq = 0;
 						if (genValid)
 						{
@@ -702,13 +787,14 @@ __global__ void __launch_bounds__(PT_WAVE) PT_PATHS_OCCUPANCY k_paths(PtPathsArg
 							uint32_t pq = item * PT_WAVE + lane;
 							// payload.seed = seed: the bounce stream starts from the state after the two jitter
 							// draws, while the raygen-local seed continues from the same state for the next sample
-							a.state[pq] = make_float4(1.0f, 1.0f, 1.0f, __uint_as_float(genSeed));
+							if (!kCarry) a.state[pq] = make_float4(1.0f, 1.0f, 1.0f, __uint_as_float(genSeed));
+							gst = make_float4(1.0f, 1.0f, 1.0f, __uint_as_float(genSeed));
 							a.rad[pq] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
 							go = o;
 							gd = d;
 							gq = pq;
 						}
-						staged = stage(genValid, go, gd, 0u, gq);
+						staged = stage(genValid, go, gd, 0u, gq, gst);
 						if (n == 0) continue;
 					}
 					else
@@ -786,13 +872,25 @@ __global__ void __launch_bounds__(PT_WAVE) PT_PATHS_OCCUPANCY k_paths(PtPathsArg
 						if (kEntryNearest && !kFlat) cur = pend ? pt_entry_first(sEntry, m, pend) : PT_TRAVERSAL_DONE;
 						else cur = pend ? pt_entry_next(sEntry, pend) : PT_TRAVERSAL_DONE;
 					}
+					if (kCarry)
+					{
+						cTx = __uint_as_float(sIn[kInState + 0][s]);
+						cTy = __uint_as_float(sIn[kInState + 1][s]);
+						cTz = __uint_as_float(sIn[kInState + 2][s]);
+						cSeed = sIn[kInState + 3][s];
+					}
 					if (kFlat)
 					{
 						best.t = __uint_as_float(sIn[kInBest + 0][s]);
-						best.prim = sIn[kInBest + 1][s];
-						best.V = __uint_as_float(sIn[kInBest + 2][s]);
-						best.W = __uint_as_float(sIn[kInBest + 3][s]);
-						best.det = __uint_as_float(sIn[kInBest + 4][s]);
+						if (kCarry)
+						{
+							best.prim = (kpack >> 24) == 0xFFu ? PT_NO_HIT : kpack >> 24;
+							kpack &= 0x00FFFFFFu;
+						}
+						else best.prim = sIn[kInBest + 1][s];
+						best.V = __uint_as_float(sIn[kInBest + (kCarry ? 1 : 2)][s]);
+						best.W = __uint_as_float(sIn[kInBest + (kCarry ? 2 : 3)][s]);
+						best.det = __uint_as_float(sIn[kInBest + (kCarry ? 3 : 4)][s]);
 					}
 				}
 				inPos += n;
@@ -1062,7 +1160,7 @@ void ptLaunchPaths(const PtPathsArgs &args, uint32_t waves, bool stats, hipStrea
 		else k_paths<false, inst, mode, PT_ENTRY_NONE><<<waves, PT_WAVE, 0, s>>>(args);              \
 	}
 	if (args.nInst) PT_LAUNCH(true, PT_NODES_GLOBAL)
-	else if (args.entry && args.entryFlat && !args.nInst)
+	else if (args.entry && args.entryFlat && !args.nInst && args.sc.nTris < 255u)  // (a primitive id is a byte in the flat kernel's rows)
 	{
 		if (stats) k_paths<true, false, PT_NODES_GLOBAL, PT_ENTRY_FLAT><<<waves, PT_WAVE, 0, s>>>(args);
 		else k_paths<false, false, PT_NODES_GLOBAL, PT_ENTRY_FLAT><<<waves, PT_WAVE, 0, s>>>(args);
