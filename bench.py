@@ -295,6 +295,8 @@ def main():
     nodes_per_ray = ts.trav_nodes / rays_stat
     tris_per_ray = ts.trav_tris / rays_stat
     p_hit = ts.trav_hits / rays_stat
+    # the flat form of k_paths (every child of the entry node is a leaf): one wide node visit per ray, no node step
+    flat_form = a.pipeline == "persistent" and ts.trav_node_steps == 0 and ts.trav_nodes == ts.rays_total and ts.bvh_tris < 255
     divergence = None
     if ts.trav_leaf_steps:
         # steps of the traversal loop only: with an entry node (pt_wave_traverse.h) a ray's first node visit -- on a flat
@@ -359,6 +361,10 @@ def main():
             # record; a survivor writes it back and makes one round trip (32 B out, 32 B in) through the wave's ring.
             # Camera rays and hit records never exist in memory.
             bytes_per_ray = 32.0 * p_prim + 16.0 * p_hit + 80.0 * p_alive
+            if flat_form:
+                # flat scenes (k_paths<.., PT_ENTRY_FLAT>): throughput and RNG state travel with the ray -- a new path only
+                # zeroes its radiance record, a survivor makes one round trip of 48 B out + 48 B in through the wave's ring
+                bytes_per_ray = 16.0 * p_prim + 96.0 * p_alive
         elif a.pipeline == "fused":
             # k_bounce (one launch per bounce): 32 B ray record read, 16 B throughput record per hit, 48 B per survivor
             bytes_per_ray = 32.0 + 16.0 * p_hit + 48.0 * p_alive
