@@ -110,9 +110,11 @@ struct pt_ctx
 	uint2 *dLcgSkip = nullptr;  // persistent pipeline: LCG skip-ahead pairs for 0, 2, 4, .. steps
 	int lcgSkipSpp = 0;
 	float4 *pState = nullptr, *pRad = nullptr, *pRingO = nullptr, *pRingD = nullptr;
-	size_t pCap = 0;                        // records in pState / pRad
+	size_t pCap = 0;                        // records in pRad
+	size_t pStateCap = 0;                   // records in pState (a flat scene only needs the ring part: ensurePersistent)
 	uint32_t lastLaunchFrames = 1;          // frames the most recent launch covered
 	int framesPerLaunch = 8;                // PT_FRAMES_PER_LAUNCH (16 buys +0.9 % at the headline config for 8.5 GB more)
+	bool framesPerLaunchSet = false;        // (set by the environment: then flat scenes do not double it)
 	unsigned char *naScratch = nullptr;     // this device's copy of `scratch` (pt_render_frames_noalloc)
 	size_t persistentBytes = 12ull << 30;   // budget for pState + pRad (PT_PERSISTENT_GB): 32 B per path per frame of a launch
 
@@ -382,7 +384,11 @@ extern "C" pt_ctx *pt_create(int device)
 	if (const char *e = getenv("PT_FRAMES_PER_LAUNCH"))
 	{
 		int v = atoi(e);
-		if (v >= 1 && v <= 256) c->framesPerLaunch = v;
+		if (v >= 1 && v <= 256)
+		{
+			c->framesPerLaunch = v;
+			c->framesPerLaunchSet = true;
+		}
 	}
 	if (const char *e = getenv("PT_PERSISTENT_GB"))
 	{
@@ -1071,21 +1077,23 @@ int ensureLcgSkip(pt_ctx *c)
 
 // Buffers of the persistent pipeline: per-path state and radiance for every frame of a launch, wave-private rings.
 // outOfMemory: set when the state/radiance pair does not fit -- the caller retries with fewer frames per launch.
-int ensurePersistent(pt_ctx *c, size_t records, bool *outOfMemory)
+// flatScene: the flat-scene kernel (pt_paths.hip) carries throughput and RNG state with the ray; of the state buffer it uses the
+// first waves * PT_PATHS_RING records as a third ring array and nothing else
+int ensurePersistent(pt_ctx *c, size_t records, bool flatScene, bool *outOfMemory)
 {
 	*outOfMemory = false;
-	// (the flat-scene kernel keeps the survivors' throughput and RNG state in the first waves * PT_PATHS_RING records of the
-	// state buffer: a third ring array, pt_paths.hip)
 	const size_t ringRecords = (size_t)c->cfg.bounceWaves * PT_PATHS_RING;
-	if (records < ringRecords) records = ringRecords;
-	if (records > c->pCap)
+	size_t stateRecords = flatScene ? ringRecords : (records < ringRecords ? ringRecords : records);
+	if (records > c->pCap || stateRecords > c->pStateCap)
 	{
 		PT_HIP(c, hipStreamSynchronize(c->stream));
 		hipFree(c->pState);
 		hipFree(c->pRad);
 		c->pState = c->pRad = nullptr;
-		c->pCap = 0;
-		hipError_t e = hipMalloc(&c->pState, records * sizeof(float4));
+		if (records < c->pCap) records = c->pCap;  // never shrink what a caller has grown
+		if (stateRecords < c->pStateCap) stateRecords = c->pStateCap;
+		c->pCap = c->pStateCap = 0;
+		hipError_t e = hipMalloc(&c->pState, stateRecords * sizeof(float4));
 		if (e == hipSuccess) e = hipMalloc(&c->pRad, records * sizeof(float4));
 		if (e != hipSuccess)
 		{
@@ -1097,6 +1105,7 @@ int ensurePersistent(pt_ctx *c, size_t records, bool *outOfMemory)
 			            records * 2 * sizeof(float4), hipGetErrorString(e));
 		}
 		c->pCap = records;
+		c->pStateCap = stateRecords;
 	}
 	if (!c->pRingO)
 	{
@@ -1117,7 +1126,10 @@ int renderPersistent(pt_ctx *c, int n, bool noAlloc = false)
 	const uint32_t WH = tile.w * tile.h;  // pixels a dispatch covers
 	const size_t nPadded = (size_t)((WH + PT_WAVE - 1) / PT_WAVE) * PT_WAVE * c->spp;  // whole pixel groups of 64
 	// frames per launch: path ids q = item * 64 + lane stay below 2^32, state + radiance stay below the memory budget
-	size_t perLaunch = (size_t)c->framesPerLaunch;
+	// the flat-scene kernel keeps no state record per path (ptLaunchPaths: the same test), so the budget buys it twice the frames
+	const bool flatScene = c->dEntry && c->entryFlat && !(c->tlasDepth ? c->nInst : 0) && c->nIdx / 3 < 255u;
+	const size_t pathBytes = flatScene && !noAlloc ? sizeof(float4) : 2 * sizeof(float4);  // (the scratch array's slices are fixed)
+	size_t perLaunch = (size_t)c->framesPerLaunch * (flatScene && !c->framesPerLaunchSet ? 2 : 1);
 	if (perLaunch * nPadded > 0xFFFFFF00ull) perLaunch = 0xFFFFFF00ull / nPadded;
 	size_t budget = c->persistentBytes;
 	if (noAlloc) budget = 2 * kNaRecBytes;
@@ -1127,11 +1139,11 @@ int renderPersistent(pt_ctx *c, int n, bool noAlloc = false)
 		size_t freeB = 0, totalB = 0;
 		if (hipMemGetInfo(&freeB, &totalB) == hipSuccess)
 		{
-			const size_t room = (freeB + c->pCap * 32) / 2;
+			const size_t room = (freeB + (c->pCap + c->pStateCap) * sizeof(float4)) / 2;
 			if (room < budget) budget = room;
 		}
 	}
-	if (perLaunch * nPadded * 32 > budget) perLaunch = budget / (nPadded * 32);
+	if (perLaunch * nPadded * pathBytes > budget) perLaunch = budget / (nPadded * pathBytes);
 	if (perLaunch < 1) perLaunch = 1;
 	if (nPadded > 0xFFFFFF00ull) return fail(c, PT_EINVAL, "pt_render_frame: %zu paths per frame exceed 2^32", nPadded);
 	hipStream_t s = c->stream;
@@ -1180,7 +1192,7 @@ int renderPersistent(pt_ctx *c, int n, bool noAlloc = false)
 		if (!noAlloc)
 		{
 			bool oom = false;
-			rc = ensurePersistent(c, nPadded * (n > 1 ? perLaunch : (size_t)batch), &oom);
+			rc = ensurePersistent(c, nPadded * (n > 1 ? perLaunch : (size_t)batch), flatScene, &oom);
 			if (rc && oom && perLaunch > 1 && n > 1)
 			{
 				perLaunch = (perLaunch + 1) / 2;
