@@ -62,7 +62,7 @@ def wall_ns(pass_dir, kernel):
 def main():
     tag_dir, kernel, commit = sys.argv[1], sys.argv[2], sys.argv[3]
     prof = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "profiles")
-    cmd = "rocprofv3 --pmc <counters> -- python3 bench.py --steps 16 --warmup 8 --no-cpu-baseline (mean over the launches of the kernel in the timed region and the warm-up; one launch = 8 frames)"
+    cmd = "rocprofv3 --pmc <counters> -- python3 bench.py --steps 16 --warmup 16 --no-cpu-baseline (mean over the launches of the kernel in the timed region and the warm-up; one launch = 16 frames)"
     # ---- HBM traffic ----
     f = load(tag_dir + "/pmc_fetch")[kernel]["FETCH_SIZE"]
     w = load(tag_dir + "/pmc_write")[kernel]["WRITE_SIZE"]
