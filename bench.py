@@ -357,14 +357,17 @@ def main():
         p_prim = paths_local / max(1.0, rays_local)
         kernel = {"persistent": "k_paths", "fused": "k_bounce"}.get(a.pipeline, "k_extend")
         if a.pipeline == "persistent":
-            # k_paths: a new path writes its 16 B state record and zeroes its 16 B radiance record; a hit reads the state
+            # k_paths: a new path writes its 16 B state record; a hit reads the state
             # record; a survivor writes it back and makes one round trip (32 B out, 32 B in) through the wave's ring.
             # Camera rays and hit records never exist in memory.
-            bytes_per_ray = 32.0 * p_prim + 16.0 * p_hit + 80.0 * p_alive
+            # The radiance record is written (16 B) only by a path that reaches a light -- at most the hits that end a path --
+            # and a new path clears one bit of the launch's mask (8 B per 64 paths) instead of zeroing it.
+            p_end = max(0.0, p_hit - p_alive)
+            bytes_per_ray = (16.0 + 0.125) * p_prim + 16.0 * p_hit + 80.0 * p_alive + 16.0 * p_end
             if flat_form:
-                # flat scenes (k_paths<.., PT_ENTRY_FLAT>): throughput and RNG state travel with the ray -- a new path only
-                # zeroes its radiance record, a survivor makes one round trip of 48 B out + 48 B in through the wave's ring
-                bytes_per_ray = 16.0 * p_prim + 96.0 * p_alive
+                # flat scenes (k_paths<.., PT_ENTRY_FLAT>): throughput and RNG state travel with the ray -- no state record;
+                # a survivor makes one round trip of 48 B out + 48 B in through the wave's ring
+                bytes_per_ray = 0.125 * p_prim + 96.0 * p_alive + 16.0 * p_end
         elif a.pipeline == "fused":
             # k_bounce (one launch per bounce): 32 B ray record read, 16 B throughput record per hit, 48 B per survivor
             bytes_per_ray = 32.0 + 16.0 * p_hit + 48.0 * p_alive

@@ -238,7 +238,7 @@ int pt_render_frames(pt_ctx *ctx, int n);
  * capture, tight serving loops and harnesses that forbid hipMalloc.  Same frames, same image, same frame counter and
  * statistics as pt_render_frames(ctx, n) on PT_PIPELINE_PERSISTENT, but every buffer pt_render_frames allocates on demand
  * (LCG skip-ahead table, per-path state and radiance, wave-private survivor rings) is a slice of a file-scope device array
- * of 16 MiB + 2 KiB that each GPU the library runs on holds until the process ends; the call makes no hipMalloc / hipFree /
+ * of 16 MiB + 34 KiB that each GPU the library runs on holds until the process ends; the call makes no hipMalloc / hipFree /
  * event creation and no host allocation.  Scene, acceleration structure, camera and the image (pt_resize) are the caller's
  * inputs and outputs as before.  Limits (PT_ELIMIT beyond them, nothing rendered): ceil(pixels of the image or tile / 64)
  * * 64 * spp_per_frame <= 2^18 paths per frame (e.g. 512 x 512 x 1 spp, 256 x 256 x 4 spp; larger images tile by tile with

@@ -43,7 +43,8 @@ constexpr size_t kNaRingBytes = (size_t)PT_NOALLOC_WAVES * PT_PATHS_RING * sizeo
 constexpr size_t kNaRecBytes = (size_t)PT_NOALLOC_MAX_RECORDS * sizeof(float4);             // 4 MiB
 constexpr size_t kNaOffRingO = 0, kNaOffRingD = kNaRingBytes, kNaOffState = 2 * kNaRingBytes,
                  kNaOffRad = 2 * kNaRingBytes + kNaRecBytes, kNaOffSkip = 2 * kNaRingBytes + 2 * kNaRecBytes;
-constexpr size_t kNaBytes = kNaOffSkip + PT_NOALLOC_MAX_SPP * sizeof(uint2);                // 16 MiB + 2 KiB
+constexpr size_t kNaOffLit = kNaOffSkip + PT_NOALLOC_MAX_SPP * sizeof(uint2);               // one bit per path: 32 KiB
+constexpr size_t kNaBytes = kNaOffLit + PT_NOALLOC_MAX_RECORDS / 8;                         // 16 MiB + 34 KiB
 constexpr int kMaxDevices = 64;
 }  // namespace
 static __device__ __align__(256) unsigned char scratch[kNaBytes];
@@ -110,6 +111,7 @@ struct pt_ctx
 	uint2 *dLcgSkip = nullptr;  // persistent pipeline: LCG skip-ahead pairs for 0, 2, 4, .. steps
 	int lcgSkipSpp = 0;
 	float4 *pState = nullptr, *pRad = nullptr, *pRingO = nullptr, *pRingD = nullptr;
+	unsigned long long *pLit = nullptr;     // one bit per record of pRad: the path has written it (PtPathsArgs::lit)
 	size_t pCap = 0;                        // records in pRad
 	size_t pStateCap = 0;                   // records in pState (a flat scene only needs the ring part: ensurePersistent)
 	uint32_t lastLaunchFrames = 1;          // frames the most recent launch covered
@@ -428,6 +430,7 @@ extern "C" void pt_destroy(pt_ctx *c)
 	hipFree(c->dLcgSkip);
 	hipFree(c->pState);
 	hipFree(c->pRad);
+	hipFree(c->pLit);
 	hipFree(c->pRingO);
 	hipFree(c->pRingD);
 	if (c->ownStream) hipStreamDestroy(c->ownStream);
@@ -1089,15 +1092,19 @@ int ensurePersistent(pt_ctx *c, size_t records, bool flatScene, bool *outOfMemor
 		PT_HIP(c, hipStreamSynchronize(c->stream));
 		hipFree(c->pState);
 		hipFree(c->pRad);
+		hipFree(c->pLit);
 		c->pState = c->pRad = nullptr;
+		c->pLit = nullptr;
 		if (records < c->pCap) records = c->pCap;  // never shrink what a caller has grown
 		if (stateRecords < c->pStateCap) stateRecords = c->pStateCap;
 		c->pCap = c->pStateCap = 0;
 		hipError_t e = hipMalloc(&c->pState, stateRecords * sizeof(float4));
 		if (e == hipSuccess) e = hipMalloc(&c->pRad, records * sizeof(float4));
+		if (e == hipSuccess) e = hipMalloc(&c->pLit, (records + 63) / 64 * sizeof(unsigned long long));
 		if (e != hipSuccess)
 		{
 			hipFree(c->pState);
+			hipFree(c->pRad);
 			c->pState = c->pRad = nullptr;
 			(void)hipGetLastError();
 			*outOfMemory = (e == hipErrorOutOfMemory);
@@ -1149,6 +1156,7 @@ int renderPersistent(pt_ctx *c, int n, bool noAlloc = false)
 	hipStream_t s = c->stream;
 	int rc = PT_OK;
 	float4 *state = nullptr, *rad = nullptr, *ringO = nullptr, *ringD = nullptr;
+	unsigned long long *lit = nullptr;
 	const uint2 *lcgSkip = nullptr;
 	uint32_t waves = c->cfg.bounceWaves;
 	if (noAlloc)
@@ -1158,6 +1166,7 @@ int renderPersistent(pt_ctx *c, int n, bool noAlloc = false)
 		ringD = reinterpret_cast<float4 *>(base + kNaOffRingD);
 		state = reinterpret_cast<float4 *>(base + kNaOffState);
 		rad = reinterpret_cast<float4 *>(base + kNaOffRad);
+		lit = reinterpret_cast<unsigned long long *>(base + kNaOffLit);
 		// the table is rebuilt on the device for every call: another context on this GPU may have left its own behind
 		ptLaunchLcgSkip((uint32_t)c->spp, reinterpret_cast<uint2 *>(base + kNaOffSkip), s);
 		lcgSkip = reinterpret_cast<const uint2 *>(base + kNaOffSkip);
@@ -1201,6 +1210,7 @@ int renderPersistent(pt_ctx *c, int n, bool noAlloc = false)
 			if (rc) return rc;
 			state = c->pState;
 			rad = c->pRad;
+			lit = c->pLit;
 			ringO = c->pRingO;
 			ringD = c->pRingD;
 		}
@@ -1236,6 +1246,7 @@ int renderPersistent(pt_ctx *c, int n, bool noAlloc = false)
 		pa.ringD = ringD;
 		pa.state = state;
 		pa.rad = rad;
+		pa.lit = lit;
 		pa.itemHead = &c->counters->chunkHead[0];
 		pa.waveRays = c->cfg.waveRays;
 		pa.spill = c->cfg.spill;
@@ -1249,7 +1260,7 @@ int renderPersistent(pt_ctx *c, int n, bool noAlloc = false)
 		pa.entryFlat = c->entryFlat ? 1u : 0u;
 		ptLaunchPaths(pa, waves, statsKernel, s);
 		if (e1) hipEventRecord(e1, s);
-		ptLaunchAccumulateItems(rad, tile, c->W, (uint32_t)c->spp, c->image, frame0, batch, c->accumMode, s);
+		ptLaunchAccumulateItems(rad, lit, tile, c->W, (uint32_t)c->spp, c->image, frame0, batch, c->accumMode, s);
 		if (e2)
 		{
 			hipEventRecord(e2, s);

@@ -350,6 +350,7 @@ __global__ void __launch_bounds__(PT_WAVE) PT_PATHS_OCCUPANCY k_paths(PtPathsArg
 	// Shades `count` (<= 64) parked hits and sends the survivors to the wave's ring.
 	auto flush = [&](uint32_t count) {
 		bool alive = false;
+		uint32_t litOut = 0;
 		float4 nT = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
 		float3x no = { 0, 0, 0 }, nd = { 0, 0, 0 };
 		uint32_t pq = 0, depth = 0;
@@ -379,6 +380,10 @@ __global__ void __launch_bounds__(PT_WAVE) PT_PATHS_OCCUPANCY k_paths(PtPathsArg
 				prim &= 0xFFu;
 			}
 			else depth = sDone[5][e] >> 16;
+			// bit 7 of the depth byte: the path has written its radiance record before (possible only where an emission does
+			// not end the path, i.e. its components do not sum to more than zero)
+			uint32_t lit = (depth >> 7) & 1u;
+			depth &= 0x7Fu;
 			if (prim != PT_NO_HIT)  // rmiss: hitValue = 0, emission = 0, terminate -> nothing to do
 			{
 				float V = __uint_as_float(sDone[0][e]), W = __uint_as_float(sDone[1][e]), det = __uint_as_float(sDone[2][e]);
@@ -417,11 +422,16 @@ __global__ void __launch_bounds__(PT_WAVE) PT_PATHS_OCCUPANCY k_paths(PtPathsArg
 				if (ex != 0.0f || ey != 0.0f || ez != 0.0f)
 				{
 					// accumDepthHitValue += emission * curAttenuation (rgen:78); one thread owns a path
-					float4 L = a.rad[pq];
+					// the record is not zeroed when the path starts: the first addition is a store of 0 + e * T and sets the
+					// path's bit in the launch's mask, which is what k_accumulate_items looks at before it reads a record
+					float4 L = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+					if (lit) L = a.rad[pq];
+					else __hip_atomic_fetch_or(PT_COLD(lit) + (pq >> 6), 1ull << (pq & 63u), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 					L.x += ex * T.x;
 					L.y += ey * T.y;
 					L.z += ez * T.z;
 					a.rad[pq] = L;
+					lit = 1u;
 				}
 				alive = (int)(depth + 1) < maxDepth && !((ex + ey) + ez > 0.0f);  // rgen:61 loop bound, rchit:56-58
 				if (alive)  // curAttenuation *= hitValue (rgen:79)
@@ -429,6 +439,7 @@ __global__ void __launch_bounds__(PT_WAVE) PT_PATHS_OCCUPANCY k_paths(PtPathsArg
 					nT = make_float4(T.x * kd.x, T.y * kd.y, T.z * kd.z, __uint_as_float(seed));
 					if (!kCarry) a.state[pq] = nT;
 				}
+				litOut = lit;
 				if (kStats) ++nHits;
 			}
 		}
@@ -440,7 +451,7 @@ __global__ void __launch_bounds__(PT_WAVE) PT_PATHS_OCCUPANCY k_paths(PtPathsArg
 		{
 			uint32_t slot = kRingLifo ? ringCount + popc64(am & lanesBelow)
 			                          : (ringHead + ringCount + popc64(am & lanesBelow)) & (PT_PATHS_RING - 1);
-			ringO[slot] = make_float4(no.x, no.y, no.z, __uint_as_float(depth + 1));
+			ringO[slot] = make_float4(no.x, no.y, no.z, __uint_as_float((depth + 1) | (litOut << 7)));
 			ringD[slot] = make_float4(nd.x, nd.y, nd.z, __uint_as_float(pq));
 			if (kCarry) ringT[slot] = nT;
 		}
@@ -789,7 +800,7 @@ __global__ void __launch_bounds__(PT_WAVE) PT_PATHS_OCCUPANCY k_paths(PtPathsArg
 							// draws, while the raygen-local seed continues from the same state for the next sample
 							if (!kCarry) a.state[pq] = make_float4(1.0f, 1.0f, 1.0f, __uint_as_float(genSeed));
 							gst = make_float4(1.0f, 1.0f, 1.0f, __uint_as_float(genSeed));
-							a.rad[pq] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+							if (lane == 0) PT_COLD(lit)[item] = 0ull;  // (instead of zeroing the item's 64 radiance records)
 							go = o;
 							gd = d;
 							gq = pq;
@@ -1077,8 +1088,8 @@ __global__ void __launch_bounds__(PT_WAVE) PT_PATHS_OCCUPANCY k_paths(PtPathsArg
 // k_accumulate for the item-major radiance layout of k_paths: q(t, i) = ((t / 64) * spp + i) * 64 + t % 64,
 // t = pixel index inside the tile.
 __global__ void __launch_bounds__(256)
-    k_accumulate_items(const float4 *rad, PtTile tile, uint32_t W, uint32_t spp, float4 *image, uint32_t lframe0,
-                       uint32_t nFrames, int mode)
+    k_accumulate_items(const float4 *rad, const unsigned long long *lit, PtTile tile, uint32_t W, uint32_t spp, float4 *image,
+                       uint32_t lframe0, uint32_t nFrames, int mode)
 {
 	uint32_t t = blockIdx.x * 256 + threadIdx.x;
 	const uint32_t WH = tile.w * tile.h;
@@ -1094,7 +1105,11 @@ __global__ void __launch_bounds__(256)
 		float ax = 0.0f, ay = 0.0f, az = 0.0f;
 		for (uint32_t i = 0; i < spp; ++i)
 		{
-			float4 L = rad[base + (size_t)i * PT_WAVE];
+			// a path that never reached a light has no record to read: its radiance is the +0 the sums start from (the word is
+			// the same for the 64 lanes of the wave: one broadcast load)
+			const size_t q = base + (size_t)i * PT_WAVE;
+			float4 L = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+			if ((lit[q >> 6] >> (t % PT_WAVE)) & 1ull) L = rad[q];
 			ax += L.x;
 			ay += L.y;
 			az += L.z;
@@ -1171,8 +1186,8 @@ void ptLaunchPaths(const PtPathsArgs &args, uint32_t waves, bool stats, hipStrea
 #undef PT_LAUNCH
 }
 
-void ptLaunchAccumulateItems(const float4 *rad, PtTile tile, uint32_t W, uint32_t spp, float4 *image, uint32_t lframe0,
-                             uint32_t nFrames, int mode, hipStream_t s)
+void ptLaunchAccumulateItems(const float4 *rad, const unsigned long long *lit, PtTile tile, uint32_t W, uint32_t spp, float4 *image,
+                             uint32_t lframe0, uint32_t nFrames, int mode, hipStream_t s)
 {
-	k_accumulate_items<<<(tile.w * tile.h + 255) / 256, 256, 0, s>>>(rad, tile, W, spp, image, lframe0, nFrames, mode);
+	k_accumulate_items<<<(tile.w * tile.h + 255) / 256, 256, 0, s>>>(rad, lit, tile, W, spp, image, lframe0, nFrames, mode);
 }

@@ -81,6 +81,9 @@ struct PtPathsArgs
 	float tmin, tmax;
 	const uint2 *lcgSkip;  // [spp]: (A, C) with lcg^(2i)(s) = A * s + C
 	float4 *ringO, *ringD, *state, *rad;
+	// one bit per path of the launch (word = work item, bit = lane): the path has added light to its radiance record.  The
+	// generator clears an item's word instead of zeroing 64 records; k_accumulate_items reads a record only where the bit is set.
+	unsigned long long *lit;
 	uint32_t *itemHead;    // zeroed per frame
 	uint32_t *waveRays;
 	uint32_t *spill;
@@ -98,8 +101,8 @@ void ptLaunchPaths(const PtPathsArgs &args, uint32_t waves, bool stats, hipStrea
 void ptLaunchStoreCamera(const PtCamera &cam, PtCamera *dst, hipStream_t s);
 // dst[i] = (A, C) with lcg^(2i)(s) = A * s + C, i < spp: the skip-ahead table of PtPathsArgs::lcgSkip, computed on the device
 void ptLaunchLcgSkip(uint32_t spp, uint2 *dst, hipStream_t s);
-void ptLaunchAccumulateItems(const float4 *rad, PtTile tile, uint32_t W, uint32_t spp, float4 *image, uint32_t lframe0,
-                             uint32_t nFrames, int mode, hipStream_t s);
+void ptLaunchAccumulateItems(const float4 *rad, const unsigned long long *lit, PtTile tile, uint32_t W, uint32_t spp, float4 *image,
+                             uint32_t lframe0, uint32_t nFrames, int mode, hipStream_t s);
 void ptLaunchAccumulate(const PtQueues &q, PtTile tile, uint32_t W, uint32_t spp, float4 *image, uint32_t lframe, int mode,
                         hipStream_t s);
 void ptLaunchDebugRng(uint32_t n, const uint32_t *v0, const uint32_t *v1, uint32_t nSteps, uint32_t *outTea,

@@ -303,3 +303,41 @@ def test_tiny_far_geometry_matches_brute_force(rt, pa, O, n_tris):
     rt.raytrace(2)
     assert np.array_equal(bits(rt.readImage()), bits(want2))
     assert rt.stats().rays_total == rays2
+
+
+@pytest.mark.parametrize("flat", [True, False])
+def test_emission_that_does_not_end_the_path(rt, pa, cornell, O, flat):
+    """rchit:56-58 ends a path only where the emission's components sum to more than zero.  A wall that emits (3, -3, 0)
+    adds to the radiance AND lets the path go on, so a path can write its radiance record several times: the first write
+    stores (the record is not zeroed beforehand, a bit in the launch's mask says it has been written), the later ones add.
+    The oracle's image, bit for bit, in the flat form (path state travels with the ray) and the tree form (state table)."""
+    from pathtracer_amd.api import PT_ACCEL_BVH4_PLOC
+    import os
+    mats = cornell.materials.copy()
+    mats[2, 3:] = (3.0, -3.0, 0.0)  # the white walls, floor and ceiling
+    mats[0, 3:] = (0.25, 0.25, -0.75)  # sum < 0
+    sc = pa.Scene(cornell.vertices, cornell.indices, mats, cornell.mat_indices)
+    osc = O.OracleScene(sc.vertices, sc.indices, sc.materials, sc.mat_indices)
+    W, H = 96, 64
+    view, proj = pa.reference_camera(W, H)
+    want, rays = osc.render(view, proj, W, H, frames=3, spp_per_frame=4, max_depth=8, seed=5)
+    old = os.environ.get("PT_NO_FLAT")
+    if not flat:
+        os.environ["PT_NO_FLAT"] = "1"
+    try:
+        rt.uploadScene(sc)
+        rt.buildBlas(None, PT_ACCEL_BVH4_PLOC)
+    finally:
+        if not flat:
+            if old is None:
+                del os.environ["PT_NO_FLAT"]
+            else:
+                os.environ["PT_NO_FLAT"] = old
+    rt.resize(W, H)
+    rt.setCamera(view, proj)
+    rt.setParams(spp_per_frame=4, max_depth=8, seed=5)
+    rt.raytrace(3)
+    img = rt.readImage()
+    assert rt.stats().rays_total == rays
+    assert np.array_equal(bits(img), bits(want))
+    assert (want[..., 1] < 0).any() and (want[..., 0] > 0).any()  # the signed emission is in the image

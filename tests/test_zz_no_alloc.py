@@ -1,6 +1,6 @@
 """GPU: pt_render_frames_noalloc -- the entry point for callers that cannot allocate (HIP graph capture, tight serving
 loops, harnesses that forbid hipMalloc).  It has no counterpart in the reference.  Same frames as pt_render_frames, on a
-file-scope device scratch array of fixed size (16 MiB + 2 KiB per GPU): up to 2^18 paths per frame (pixels rounded up to
+file-scope device scratch array of fixed size (16 MiB + 34 KiB per GPU): up to 2^18 paths per frame (pixels rounded up to
 64, times spp_per_frame) and 256 spp per frame.  Checked against pt_render_frames through the C ABI, bit for bit, on two
 calls in a row, the second with a smaller input; oversize inputs are refused with PT_ELIMIT."""
 import numpy as np
