@@ -12,7 +12,11 @@
 //     no chunk bookkeeping) and come back through the staging phase, preferred over new paths -- so a path
 //     stays in the wave that started it from its first ray to its last;
 //   * the per-path state that is only needed at a hit (throughput, rng state) lives in one 16-byte record
-//     state[q], the radiance in rad[q], q = item * 64 + lane: a staging batch touches 1 KB contiguous.
+//     state[q], q = item * 64 + lane (a staging batch touches 1 KB contiguous) -- or, for a flat scene (every
+//     child of the entry node a leaf), travels with the ray: a third ring record, four more staging and done
+//     rows, four registers of the lane, and no table the shading pass would have to gather from;
+//   * the radiance rad[q] is written only by a path that reaches a light; lit[item] holds one bit per path
+//     ("written") that the generator clears and k_accumulate_items consults before it reads a record.
 // One tail per frame instead of one per bounce.  Every arithmetic step that reaches a result is the shared
 // specification (pt_device_common.h, pt_wave_traverse.h): images are bit-identical to the other pipelines
 // and to the CPU oracle.

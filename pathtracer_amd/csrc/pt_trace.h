@@ -62,7 +62,8 @@ void ptLaunchBounce(const PtSceneDev &sc, const PtQueues &q, int in, PtFrameCoun
 // Persistent path kernel (pt_paths.hip): one launch traces every path of the frame from camera ray to
 // termination.  Buffers: ringO/ringD = waves * PT_PATHS_RING records (wave-private survivor rings), state and
 // rad = nFrames * ceil(tile pixels/64) * 64 * spp records in item-major order q = ((t / 64) * spp + sample) * 64 + t % 64
-// (t = pixel index inside the tile).
+// (t = pixel index inside the tile), lit = one 64-bit word per 64 of them.  A flat scene uses the first waves *
+// PT_PATHS_RING records of `state` as a third ring (throughput, RNG state) and the rest of it not at all.
 #define PT_PATHS_RING 256u
 struct PtPathsArgs
 {
