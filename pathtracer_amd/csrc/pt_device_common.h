@@ -470,42 +470,12 @@ __device__ __forceinline__ float3x pt_sample_texture(const float4 *tex, uint32_t
 // (c0*x + c1*y) + (c2*z + c3*1); worldHitNormal = normalize(vec3(localHitNormal * gl_WorldToObjectEXT)), a row
 // vector times the matrix.  xf == nullptr is the reference's single identity instance (no transform arithmetic).
 // kd = hitValue of rchit:54 (the material's diffuse colour, times the diffuse map when the scene has one), ke = emission.
+// The arithmetic of a hit once its three vertices are known (rchit:39-53): interpolation, the instance's transform, the new ray.
 template <bool kInRange = false>
-__device__ __forceinline__ void pt_shade_hit(const PtSceneDev &sc, uint32_t prim, float u, float v, uint32_t &seed,
-                                         float3x &o, float3x &d, float3x &kd, float3x &ke, const float *xf = nullptr)
+__device__ __forceinline__ void pt_shade_math(const float p0[3], const float p1[3], const float p2[3], const float n0[3],
+                                              const float n1[3], const float n2[3], float bx, float by, float bz,
+                                              uint32_t &seed, float3x &o, float3x &d, const float *xf)
 {
-	float bx = (1.0f - u) - v, by = u, bz = v;
-	float p0[3], p1[3], p2[3], n0[3], n1[3], n2[3];
-	if (sc.shade && !sc.texture)
-	{
-		const float4 *r = reinterpret_cast<const float4 *>(sc.shade + prim);
-		const float4 a = r[0], b = r[1], c = r[2], e = r[3], f = r[4], g = r[5];
-		p0[0] = a.x; p0[1] = a.y; p0[2] = a.z; p1[0] = a.w; p1[1] = b.x; p1[2] = b.y; p2[0] = b.z; p2[1] = b.w; p2[2] = c.x;
-		n0[0] = c.y; n0[1] = c.z; n0[2] = c.w; n1[0] = e.x; n1[1] = e.y; n1[2] = e.z; n2[0] = e.w; n2[1] = f.x; n2[2] = f.y;
-		kd = { f.z, f.w, g.x };
-		ke = { g.y, g.z, g.w };
-	}
-	else
-	{
-		const float *mat = sc.materials[sc.matIndices[prim]].diffuse;
-		kd = { mat[0], mat[1], mat[2] };
-		ke = { mat[3], mat[4], mat[5] };
-		const float *v0 = sc.vertices[sc.indices[3 * (size_t)prim + 0]].pos;
-		const float *v1 = sc.vertices[sc.indices[3 * (size_t)prim + 1]].pos;
-		const float *v2 = sc.vertices[sc.indices[3 * (size_t)prim + 2]].pos;
-#pragma unroll
-		for (int k = 0; k < 3; ++k)
-		{
-			p0[k] = v0[k]; p1[k] = v1[k]; p2[k] = v2[k];
-			n0[k] = v0[3 + k]; n1[k] = v1[3 + k]; n2[k] = v2[3 + k];
-		}
-		if (sc.texture)
-		{
-			float tu = (v0[9] * bx + v1[9] * by) + v2[9] * bz, tv = (v0[10] * bx + v1[10] * by) + v2[10] * bz;
-			float3x tx = pt_sample_texture(sc.texture, sc.texW, sc.texH, tu, tv);
-			kd = { kd.x * tx.x, kd.y * tx.y, kd.z * tx.z };
-		}
-	}
 	float3x N, P;
 	N.x = (n0[0] * bx + n1[0] * by) + n2[0] * bz;
 	N.y = (n0[1] * bx + n1[1] * by) + n2[1] * bz;
@@ -530,5 +500,48 @@ __device__ __forceinline__ void pt_shade_hit(const PtSceneDev &sc, uint32_t prim
 	float3x rv = pt_rnd_unit_vector<kInRange>(seed);
 	d = pt_normalize<kInRange>({ Nn.x + rv.x, Nn.y + rv.y, Nn.z + rv.z });
 	o = P;
+}
+
+template <bool kInRange = false>
+__device__ __forceinline__ void pt_shade_hit(const PtSceneDev &sc, uint32_t prim, float u, float v, uint32_t &seed,
+                                         float3x &o, float3x &d, float3x &kd, float3x &ke, const float *xf = nullptr)
+{
+	float bx = (1.0f - u) - v, by = u, bz = v;
+	float p0[3], p1[3], p2[3], n0[3], n1[3], n2[3];
+	if (sc.shade && !sc.texture)
+	{
+		const float4 *r = reinterpret_cast<const float4 *>(sc.shade + prim);
+		const float4 a = r[0], b = r[1], c = r[2], e = r[3], f = r[4], g = r[5];
+		p0[0] = a.x; p0[1] = a.y; p0[2] = a.z; p1[0] = a.w; p1[1] = b.x; p1[2] = b.y; p2[0] = b.z; p2[1] = b.w; p2[2] = c.x;
+		n0[0] = c.y; n0[1] = c.z; n0[2] = c.w; n1[0] = e.x; n1[1] = e.y; n1[2] = e.z; n2[0] = e.w; n2[1] = f.x; n2[2] = f.y;
+		kd = { f.z, f.w, g.x };
+		ke = { g.y, g.z, g.w };
+		// (the arithmetic is instantiated in both branches: joined behind them, the eighteen loaded values are first copied
+		// into the registers the other branch would have put them in)
+		pt_shade_math<kInRange>(p0, p1, p2, n0, n1, n2, bx, by, bz, seed, o, d, xf);
+		return;
+	}
+	else
+	{
+		const float *mat = sc.materials[sc.matIndices[prim]].diffuse;
+		kd = { mat[0], mat[1], mat[2] };
+		ke = { mat[3], mat[4], mat[5] };
+		const float *v0 = sc.vertices[sc.indices[3 * (size_t)prim + 0]].pos;
+		const float *v1 = sc.vertices[sc.indices[3 * (size_t)prim + 1]].pos;
+		const float *v2 = sc.vertices[sc.indices[3 * (size_t)prim + 2]].pos;
+#pragma unroll
+		for (int k = 0; k < 3; ++k)
+		{
+			p0[k] = v0[k]; p1[k] = v1[k]; p2[k] = v2[k];
+			n0[k] = v0[3 + k]; n1[k] = v1[3 + k]; n2[k] = v2[3 + k];
+		}
+		if (sc.texture)
+		{
+			float tu = (v0[9] * bx + v1[9] * by) + v2[9] * bz, tv = (v0[10] * bx + v1[10] * by) + v2[10] * bz;
+			float3x tx = pt_sample_texture(sc.texture, sc.texW, sc.texH, tu, tv);
+			kd = { kd.x * tx.x, kd.y * tx.y, kd.z * tx.z };
+		}
+	}
+	pt_shade_math<kInRange>(p0, p1, p2, n0, n1, n2, bx, by, bz, seed, o, d, xf);
 }
 

@@ -354,10 +354,12 @@ __global__ void __launch_bounds__(PT_WAVE) PT_PATHS_OCCUPANCY k_paths(PtPathsArg
 	// Shades `count` (<= 64) parked hits and sends the survivors to the wave's ring.
 	auto flush = [&](uint32_t count) {
 		bool alive = false;
-		uint32_t litOut = 0;
-		float4 nT = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-		float3x no = { 0, 0, 0 }, nd = { 0, 0, 0 };
-		uint32_t pq = 0, depth = 0;
+		// (what follows is read by survivors only, and every survivor has written it: left uninitialised on purpose -- zeros
+		// for the other lanes are a dozen moves per pass)
+		uint32_t litOut;
+		float4 nT;
+		float3x no, nd;
+		uint32_t pq, depth;
 		const int maxDepth = PT_COLD(maxDepth);
 		// what the shading reads: the per-primitive records, or (no records / a diffuse map) the reference's gather
 		PtSceneDev fsc = {};
@@ -510,12 +512,14 @@ __global__ void __launch_bounds__(PT_WAVE) PT_PATHS_OCCUPANCY k_paths(PtPathsArg
 		}
 		// flat scene: box test and the first leaf here, with all 64 lanes; then the ray is finished (hit: parked for the
 		// shading pass; nothing hit: gone) or goes -- ballot-packed -- to the staging area with what it has found so far
-		PtLaneRay pr = {};
-		PtBest b = { tmax, PT_NO_HIT, 0.0f, 0.0f, 1.0f };
-		uint32_t m = 0;
+		// (pr, b, m: read behind `valid &&` only -- no zeros for the lanes of a partial batch)
+		PtLaneRay pr;
+		PtBest b;
+		uint32_t m;
 		PT_T_PIN(o.x) PT_T_PIN(d.x) PT_T_MARK(PT_T_S_PREPARE)
 		if (valid)
 		{
+			b = { tmax, PT_NO_HIT, 0.0f, 0.0f, 1.0f };
 			pr = pt_prepare_ray<true>(o, d);
 #ifdef PT_PROBE_VALU
 			{
