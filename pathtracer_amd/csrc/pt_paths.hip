@@ -17,6 +17,10 @@
 //     rows, four registers of the lane, and no table the shading pass would have to gather from;
 //   * the radiance rad[q] is written only by a path that reaches a light; lit[item] holds one bit per path
 //     ("written") that the generator clears and k_accumulate_items consults before it reads a record.
+// The ring holds at most 254 records.  Rays of a wave are in the ring (R), in the staging area (S), in lanes (L <= 64) or parked
+// for the shading pass (D); only the generator adds rays, 64 at a time, and it runs only when R <= 63 (survivors are preferred),
+// S = 0 (the staging area is empty) and D <= 63 (64 parked hits are shaded before anything else is staged): R + S + L + D <= 190
+// before it and <= 254 after it, and every other step moves rays between the four or drops them.
 // One tail per frame instead of one per bounce.  Every arithmetic step that reaches a result is the shared
 // specification (pt_device_common.h, pt_wave_traverse.h): images are bit-identical to the other pipelines
 // and to the CPU oracle.
