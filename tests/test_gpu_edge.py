@@ -23,7 +23,8 @@ def test_empty_scene_renders_black(rt, pa):
     assert np.all(rt.debugPrimaryHits()["prim"] == 0xFFFFFFFF)
 
 
-@pytest.mark.parametrize("W,H,spp,depth", [(1, 1, 1, 1), (7, 5, 3, 2), (257, 3, 2, 8), (63, 65, 5, 20), (130, 2, 17, 3)])
+@pytest.mark.parametrize("W,H,spp,depth", [(1, 1, 1, 1), (7, 5, 3, 2), (257, 3, 2, 8), (63, 65, 5, 20), (130, 2, 17, 3),
+                                           (40, 30, 2, 64)])  # (64: the largest depth; it shares a byte with a flag)
 def test_ragged_extents_bit_exact(rt, pa, cornell, ocornell, W, H, spp, depth):
     view, proj = pa.reference_camera(W, H)
     rt.buildBlas(cornell)
