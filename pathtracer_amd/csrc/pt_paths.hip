@@ -1103,28 +1103,50 @@ __global__ void __launch_bounds__(256)
     k_accumulate_items(const float4 *rad, const unsigned long long *lit, PtTile tile, uint32_t W, uint32_t spp, float4 *image,
                        uint32_t lframe0, uint32_t nFrames, int mode)
 {
-	uint32_t t = blockIdx.x * 256 + threadIdx.x;
+	// (no early return: the lanes of a wave fetch the mask words for one another)
 	const uint32_t WH = tile.w * tile.h;
-	if (t >= WH) return;
+	const uint32_t tt = blockIdx.x * 256 + threadIdx.x, lane = threadIdx.x & (PT_WAVE - 1);
+	const bool valid = tt < WH;
+	const uint32_t t = valid ? tt : 0u;
 	const uint32_t p = (tile.y0 + t / tile.w) * W + tile.x0 + t % tile.w;  // image pixel of tile pixel t
 	const size_t framePitch = (size_t)((WH + PT_WAVE - 1) / PT_WAVE) * spp * PT_WAVE;
-	size_t base = (size_t)(t / PT_WAVE) * spp * PT_WAVE + (t % PT_WAVE);
+	size_t base = (size_t)(tt / PT_WAVE) * spp * PT_WAVE + lane;  // (tt / 64 is the same for the 64 lanes of a wave)
 	const float S = (float)spp;
-	float4 out = lframe0 ? image[p] : make_float4(0.0f, 0.0f, 0.0f, 1.0f);
+	float4 out = (lframe0 && valid) ? image[p] : make_float4(0.0f, 0.0f, 0.0f, 1.0f);
 	// the frames of the launch one after the other, exactly as if each had been a dispatch of its own
 	for (uint32_t f = 0; f < nFrames; ++f, base += framePitch)
 	{
 		float ax = 0.0f, ay = 0.0f, az = 0.0f;
-		for (uint32_t i = 0; i < spp; ++i)
+		// A path that never reached a light has no record to read: its radiance is the +0 the sums start from.  The words of
+		// the pixel group's samples are consecutive: one coalesced load per 64 samples, lane j holding sample j's word; the
+		// records of four samples are requested together and added in sample order.
+		const unsigned long long *words = lit + (base >> 6);
+		for (uint32_t c = 0; c < spp; c += PT_WAVE)
 		{
-			// a path that never reached a light has no record to read: its radiance is the +0 the sums start from (the word is
-			// the same for the 64 lanes of the wave: one broadcast load)
-			const size_t q = base + (size_t)i * PT_WAVE;
-			float4 L = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-			if ((lit[q >> 6] >> (t % PT_WAVE)) & 1ull) L = rad[q];
-			ax += L.x;
-			ay += L.y;
-			az += L.z;
+			const uint32_t n = spp - c < PT_WAVE ? spp - c : PT_WAVE;
+			const unsigned long long mine = lane < n ? words[c + lane] : 0ull;
+			const uint32_t lo = (uint32_t)mine, hi = (uint32_t)(mine >> 32);
+			for (uint32_t j = 0; j < n; j += 4)
+			{
+				float4 L[4];
+#pragma unroll
+				for (uint32_t k = 0; k < 4; ++k)
+				{
+					const uint32_t jj = j + k < n ? j + k : n - 1u;  // (uniform)
+					const uint32_t wl = __builtin_amdgcn_readlane(lo, jj), wh = __builtin_amdgcn_readlane(hi, jj);
+					const bool on = valid && j + k < n && (((lane < 32u ? wl : wh) >> (lane & 31u)) & 1u);
+					L[k] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+					if (on) L[k] = rad[base + (size_t)(c + j + k) * PT_WAVE];
+				}
+#pragma unroll
+				for (uint32_t k = 0; k < 4; ++k)
+					if (j + k < n)
+					{
+						ax += L[k].x;
+						ay += L[k].y;
+						az += L[k].z;
+					}
+			}
 		}
 		float cx = ax / S, cy = ay / S, cz = az / S;
 		const uint32_t lframe = lframe0 + f;
@@ -1137,7 +1159,7 @@ __global__ void __launch_bounds__(256)
 			out = make_float4(out.x * be + cx * al, out.y * be + cy * al, out.z * be + cz * al, 1.0f);  // mix(old,new,a)
 		}
 	}
-	image[p] = out;
+	if (valid) image[p] = out;
 }
 }  // namespace
 
