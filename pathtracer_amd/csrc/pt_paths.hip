@@ -1103,9 +1103,11 @@ __global__ void __launch_bounds__(256)
     k_accumulate_items(const float4 *rad, const unsigned long long *lit, PtTile tile, uint32_t W, uint32_t spp, float4 *image,
                        uint32_t lframe0, uint32_t nFrames, int mode)
 {
-	// (no early return: the lanes of a wave fetch the mask words for one another)
+	// (a lane past the last pixel stays: the lanes of a wave fetch the mask words for one another; a WAVE past it leaves --
+	// its pixel group does not exist, nor do its mask words)
 	const uint32_t WH = tile.w * tile.h;
 	const uint32_t tt = blockIdx.x * 256 + threadIdx.x, lane = threadIdx.x & (PT_WAVE - 1);
+	if (tt - lane >= WH) return;
 	const bool valid = tt < WH;
 	const uint32_t t = valid ? tt : 0u;
 	const uint32_t p = (tile.y0 + t / tile.w) * W + tile.x0 + t % tile.w;  // image pixel of tile pixel t
