@@ -24,7 +24,8 @@ def test_empty_scene_renders_black(rt, pa):
 
 
 @pytest.mark.parametrize("W,H,spp,depth", [(1, 1, 1, 1), (7, 5, 3, 2), (257, 3, 2, 8), (63, 65, 5, 20), (130, 2, 17, 3),
-                                           (40, 30, 2, 64)])  # (64: the largest depth; it shares a byte with a flag)
+                                           (40, 30, 2, 64),   # (64: the largest depth; it shares a byte with a flag)
+                                           (9, 7, 70, 6)])    # (more than 64 samples: k_accumulate_items fetches the mask in 64s)
 def test_ragged_extents_bit_exact(rt, pa, cornell, ocornell, W, H, spp, depth):
     view, proj = pa.reference_camera(W, H)
     rt.buildBlas(cornell)
