@@ -65,6 +65,12 @@ def parse(argv=None):
                          "configs[2] (viking_room.obj with a 1024^2 diffuse map, use --width 3840 --height 2160); teapot = configs[3] "
                          "(teapot.obj x 64x64 instances) -- both meshes from tests/golden/ref_seam.npz, one light quad added")
     ap.add_argument("--tris", type=float, default=1e6, help="--scene soup: number of triangles")
+    ap.add_argument("--scaling", choices=["weak", "strong"], default="weak",
+                    help="--split streams only.  weak: every rank renders --steps frames (N x the samples).  strong: --steps is the "
+                         "TOTAL number of frames (configs[1]: a fixed 1024 spp), rank r renders the global frames r, r+N, ... below it")
+    ap.add_argument("--cpu-sample-pixels", type=int, default=0,
+                    help="cpu_baseline of the scenes other than cornell: pixels of the first timed sample (0 = 2048; a second, "
+                         "larger sample is sized from it to ~8 s of CPU work)")
     ap.add_argument("--force-dist", action="store_true",
                     help="go through torch.distributed/RCCL even for one rank (rehearses the N>1 path on one GPU)")
     return ap.parse_args(argv)
@@ -152,9 +158,22 @@ def kernel_source_hash():
     return h.hexdigest()[:16]
 
 
-def load_profile_json(name):
+# the per-ray counter constants are a property of (kernel instantiation, workload): one pair of summaries per scene
+PROFILE_SUFFIX = {"cornell": "", "viking": "_viking", "teapot": "_teapot", "soup": "_soup"}
+
+
+def workload_key(a):
+    """What a PMC summary must have been taken on for its per-ray constants to price this run (the number of frames does
+    not enter: the constants are per ray)."""
+    k = f"{a.scene} {a.width}x{a.height} spp{a.spp_per_frame} depth{a.depth} {a.builder} {a.pipeline}"
+    if a.scene == "soup":
+        k += f" tris{int(a.tris)}"
+    return k
+
+
+def load_profile_json(name, workload=None):
     """A committed PMC summary (profiles/), or None when there is none -- or when it was taken on other kernel sources than
-    the ones in this tree: counter constants of another kernel must not price this one."""
+    the ones in this tree, or on another workload: counter constants of another kernel must not price this one."""
     try:
         with open(os.path.join(ROOT, "profiles", name)) as f:
             d = json.load(f)
@@ -163,6 +182,10 @@ def load_profile_json(name):
     if d.get("kernel_sources_sha") and d["kernel_sources_sha"] != kernel_source_hash():
         sys.stderr.write(f"bench.py: profiles/{name} was taken on other kernel sources ({d.get('commit')}); its counter "
                          "constants are not used (regenerate: scripts/gpu_round_profile.sh + scripts/collect_profile.sh)\n")
+        return None
+    if workload and d.get("workload") and d["workload"] != workload:
+        sys.stderr.write(f"bench.py: profiles/{name} was taken on '{d['workload']}', this run is '{workload}'; its counter "
+                         "constants are not used\n")
         return None
     return d
 
@@ -260,6 +283,14 @@ def main():
     rt.setCamera(view, proj)
     rt.setParams(spp_per_frame=S, max_depth=D, tmin=1e-3, tmax=tmax, seed=0, max_frames=0)
     tiles = a.split == "tiles"
+    strong = a.scaling == "strong" and not tiles
+    if strong and a.steps < world:
+        raise SystemExit(f"--scaling strong: {a.steps} frames cannot be split over {world} ranks")
+
+    def local_frames(total):
+        """frames this rank renders of `total`: all of them (weak scaling, tiles), or its share r, r+N, ... < total (strong)"""
+        return multigpu.strong_frame_count(rank, world, total) if strong else total
+
     if tiles:
         rt.setFrameSchedule(first=0, stride=1)  # every rank renders the same frames ...
         rt.setTile(*multigpu.tile_schedule(rank, world, W, H))  # ... on its own column strip
@@ -318,7 +349,7 @@ def main():
     rt.resetFrame()
     rt.resetStats()
     if a.warmup > 0:
-        run(a.warmup)
+        run(max(1, local_frames(a.warmup)))
     rt.resetFrame()
     rt.resetStats()
     rt.setProfiling(PT_PROFILE_KERNELS)
@@ -326,7 +357,7 @@ def main():
     # ---- timed region: exactly K steps ----
     barrier()
     t0 = time.perf_counter()
-    run(a.steps)
+    run(local_frames(a.steps))
     barrier()
     dt = time.perf_counter() - t0
 
@@ -345,17 +376,18 @@ def main():
     if a.out_image and rank == 0:
         img = rt.readImage()
         if dist is not None:
-            multigpu.finalize_mean(img, a.steps if tiles else world * a.steps)
+            multigpu.finalize_mean(img, a.steps if (tiles or strong) else world * a.steps)
         np.save(a.out_image, img)
 
     if rank == 0:
         mrays = rays_all / dt_max / 1e6
-        total_spp = a.steps * S * (1 if tiles else world)
+        total_spp = a.steps * S * (1 if (tiles or strong) else world)
         scene_bytes = st.bvh_nodes * 64.0 + 3 * st.bvh_tris * 48.0
-        paths_local = float(st.paths_last_frame) * a.steps
+        paths_local = float(st.paths_last_frame) * local_frames(a.steps)
         p_alive = max(0.0, (rays_local - paths_local) / max(1.0, rays_local))  # rays of bounce >= 1 = survivors
         p_prim = paths_local / max(1.0, rays_local)
         kernel = {"persistent": "k_paths", "fused": "k_bounce"}.get(a.pipeline, "k_extend")
+        cache_bytes_per_ray = nodes_per_ray * 64.0 + tris_per_ray * 48.0
         if a.pipeline == "persistent":
             # k_paths: a new path writes its 16 B state record; a hit reads the state
             # record; a survivor writes it back and makes one round trip (32 B out, 32 B in) through the wave's ring.
@@ -374,18 +406,23 @@ def main():
         else:
             # k_extend: 32 B ray record read + 16 B hit record written
             bytes_per_ray = 48.0
-        cache_bytes_per_ray = nodes_per_ray * 64.0 + tris_per_ray * 48.0
         # whole-step figure of SURVEY.md 8(d): 160 B queue traffic + traversal + 172 B closest-hit gather
         bytes_per_ray_step = 160.0 + nodes_per_ray * 64.0 + tris_per_ray * 48.0 + 172.0 * p_hit
         launches = max(1, st.extend_launches)
         ext_ms = st.extend_ms_total / launches
         rays_per_launch = rays_local / launches
         sec = ext_ms * 1e-3
-        hbm_achieved = (rays_per_launch * bytes_per_ray + scene_bytes) / sec / 1e9 if sec > 0 else 0.0
+        # A scene whose node + triangle arrays exceed the 256 MiB Infinity Cache cannot be cache-resident: its traversal
+        # fetches (n_nodes x 64 B + n_tris x 48 B per ray) are HBM traffic and count as algorithmic bytes;
+        # below that size they are served by L1/L2/MALL and are reported separately (cache_served_*).
+        traversal_from_hbm = scene_bytes > 256.0 * 2 ** 20
+        if traversal_from_hbm:
+            bytes_per_ray += cache_bytes_per_ray
+        hbm_achieved = (rays_per_launch * bytes_per_ray + (0.0 if traversal_from_hbm else scene_bytes)) / sec / 1e9 if sec > 0 else 0.0
         # hardware-counter constants of this kernel on this workload, from the committed --pmc summaries (per RAY, so that
         # they compare with bytes_per_ray whatever the launch length)
-        tj = load_profile_json({"persistent": "traffic_paths.json", "fused": "traffic_bounce.json"}.get(a.pipeline, "none")) \
-            if a.scene == "cornell" else None
+        sfx, wkey = PROFILE_SUFFIX[a.scene], workload_key(a)
+        tj = load_profile_json({"persistent": f"traffic_paths{sfx}.json", "fused": "traffic_bounce.json"}.get(a.pipeline, "none"), wkey)
         traffic_per_ray = tj.get("hbm_bytes_per_ray") if tj else None
         traffic = round(traffic_per_ray * rays_per_launch) if traffic_per_ray else None
         hbm = {"bound": "hbm", "achieved": round(hbm_achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
@@ -395,10 +432,12 @@ def main():
                "traffic_over_algorithmic": round(traffic_per_ray / bytes_per_ray, 3) if traffic_per_ray else None,
                "kernel": kernel, "launch_ms": round(ext_ms, 4), "rays_per_launch": rays_per_launch,
                "p_alive": round(p_alive, 4), "p_hit": round(p_hit, 4),
+               "traversal_bytes_counted": traversal_from_hbm, "scene_bytes": scene_bytes,
+               "profile": tj.get("source") if tj else None,
                "cache_served_bytes_per_ray": round(cache_bytes_per_ray, 2),
                "cache_served_gbs": round(rays_per_launch * cache_bytes_per_ray / sec / 1e9, 1) if sec > 0 else 0.0,
                "nodes_per_ray": round(nodes_per_ray, 3), "tris_per_ray": round(tris_per_ray, 3)}
-        vj = load_profile_json("valu_paths.json") if (a.pipeline == "persistent" and a.scene == "cornell") else None
+        vj = load_profile_json(f"valu_paths{sfx}.json", wkey) if a.pipeline == "persistent" else None
         valu = None
         if vj and vj.get("valu_wave_insts_per_ray"):
             ipr = float(vj["valu_wave_insts_per_ray"])
@@ -407,11 +446,13 @@ def main():
             valu = {"bound": "valu", "achieved": round(ginst, 2), "peak": VALU_PEAK_GINST, "unit": "Ginst/s",
                     "frac": round(ginst / VALU_PEAK_GINST, 5), "traffic": traffic,
                     "note": "VALU wave-instruction issue: achieved = SQ_INSTS_VALU per ray (committed rocprofv3 --pmc pass, "
-                            "profiles/valu_paths.json) x rays per launch / launch duration (live); peak = 256 CUs x 4 SIMDs x "
+                            f"profiles/valu_paths{sfx}.json) x rays per launch / launch duration (live); peak = 256 CUs x 4 SIMDs x "
                             "2.4 GHz / 2 cycles per wave64 instruction.  Cheapest-instruction peak: cmp/cndmask/cvt/min/max "
                             "issue at ~1.5x and rcp/sqrt at ~3x that cost, so 1.0 is not reachable by this mix",
                     "kernel": kernel, "launch_ms": round(ext_ms, 4), "rays_per_launch": rays_per_launch,
                     "valu_wave_insts_per_ray": round(ipr, 3), "valu_lane_util": vj.get("valu_lane_util"),
+                    "wait_any_share_of_wave_cycles": vj.get("wait_any_share"), "l2_hit_rate": vj.get("l2_hit_rate"),
+                    "kernel_instantiation": vj.get("kernel"),
                     "clock_ghz_held_in_profile": held,
                     "frac_at_held_clock": round(ginst / (CUS * SIMDS_PER_CU * held / 2.0), 5),
                     "extend_mrays_per_s": round(rays_per_launch / sec / 1e6, 1) if sec > 0 else 0.0,
@@ -424,15 +465,16 @@ def main():
         out = {
             "metric": "Mrays/s", "value": round(mrays, 2), "unit": "Mrays/s", "n_gpus": world, "steps": a.steps,
             "warmup": a.warmup, "ms_per_step": round(dt_max / a.steps * 1e3, 4), "higher_is_better": True,
-            "scaling": "strong" if tiles else "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "scaling": "strong" if (tiles or strong) else "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": f"{scene_name} {W}x{H}, {S} spp/frame x {a.steps} frames"
-                                   f"{'' if tiles else '/GPU'}, max depth {D}, persistent wavefront path tracer, quantised BVH4 "
+                                   f"{'' if (tiles or strong) else '/GPU'}, max depth {D}, persistent wavefront path tracer, quantised BVH4 "
                                    f"({a.builder.upper()})" + {"cornell": " (BASELINE.json configs[1])", "soup": " (BASELINE.json configs[4] generator)",
                                                              "viking": " (BASELINE.json configs[2])", "teapot": " (BASELINE.json configs[3])"}[a.scene],
                        "width": W, "height": H, "spp_per_frame": S, "max_depth": D, "total_spp": total_spp,
-                       "parallelism": (f"image tiles (column strips) x{world}" if tiles else f"sample-stream x{world}")},
+                       "parallelism": (f"image tiles (column strips) x{world}" if tiles else
+                                       f"sample-stream x{world}" + (" (frames of one fixed total split across the ranks)" if strong else ""))},
             "samples_per_px_per_s": round(total_spp / dt_max, 3),
-            "rays_per_step_per_gpu": rays_local / a.steps,
+            "rays_per_step_per_gpu": rays_local / max(1, local_frames(a.steps)),
             "roofline": roofline, other_key: other,
             "roofline_step": {"note": "SURVEY.md 8(d) whole-step formula; its traversal/gather terms are L1/L2 traffic on a "
                                       "cache-resident scene, so frac may exceed 1 -- HBM-only accounting is roofline_hbm",
@@ -445,13 +487,17 @@ def main():
                           round(st.shade_ms_total / max(1, st.shade_launches), 4),
                           "launches": int(st.extend_launches)},
             "pipeline": a.pipeline, "builder": a.builder, "split": a.split, "divergence": divergence,
+            "profile_workload": workload_key(a), "bench_args": " ".join(sys.argv[1:]),
             "bvh": {"nodes": st.bvh_nodes, "depth": st.bvh_depth, "tris": st.bvh_tris, "build_ms": round(st.build_ms, 3)},
             "distributed": ({"backend": "nccl (RCCL)", "rccl_version": rccl, "world_size": world,
                              "launcher": "torch.distributed.run"} if dist is not None else None),
             "reference_lavapipe": probe_lavapipe(),
         }
-        if world == 1 and not a.no_cpu_baseline and a.scene == "cornell":
-            out["cpu_baseline"] = cpu_baseline(scene, view, proj, W, H, S, D, a.cpu_sample_frames)
+        if world == 1 and not a.no_cpu_baseline:
+            if a.scene == "cornell":
+                out["cpu_baseline"] = cpu_baseline(scene, view, proj, W, H, S, D, a.cpu_sample_frames)
+            else:
+                out["cpu_baseline"] = cpu_baseline_pixels(a, scene, view, proj, tmax)
         print(json.dumps(out), flush=True)
 
     rt.cleanup()
@@ -472,6 +518,44 @@ def cpu_baseline(scene, view, proj, W, H, S, D, frames):
     return {"value": round(rays / dt / 1e6, 3), "unit": "Mrays/s", "cores": threads, "kind": "port",
             "sample": f"{frames} frame(s) of {W}x{H} x {S} spp, depth {D} (global frame 1..), {rays} rays in {dt:.2f} s",
             "samples_per_px_per_s": round(frames * S / dt, 4)}
+
+
+def cpu_baseline_pixels(a, scene, view, proj, tmax, budget_s=8.0):
+    """The same oracle on a bounded PIXEL sample of the workload (the scenes whose full frame would take the CPU minutes):
+    a seeded random set of pixels of global frame 1 (jittered), all spp and bounces of each; rays/s = rays traced / wall.
+    A first sample sizes a second one to ~budget_s of CPU work; the second is the one reported.  For a two-level scene
+    the oracle has no top-level structure (its definition is "every instance": one root-box test per instance and ray),
+    which is what its rate then measures."""
+    import numpy as np
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import oracle as O
+    n_tris = scene.n_tris
+    if a.instances is None and n_tris > 5_000_000:
+        return {"value": None, "unit": "Mrays/s", "cores": O.max_threads(), "kind": "port",
+                "sample": f"not run: the oracle's single-threaded BVH2 build over {n_tris} triangles takes minutes; "
+                          "run --scene soup --tris 1e6 for the CPU rate on the same generator"}
+    t0 = time.perf_counter()
+    osc = O.OracleScene(scene.vertices, scene.indices, scene.materials, scene.mat_indices, instances=a.instances,
+                        texture=a.texture)
+    build_s = time.perf_counter() - t0
+    W, H, S, D = a.width, a.height, a.spp_per_frame, a.depth
+    rng = np.random.default_rng(5)
+
+    def sample(n):
+        px = rng.choice(W * H, size=min(n, W * H), replace=False).astype(np.uint32)
+        t = time.perf_counter()
+        _, rays = osc.render_pixels(view, proj, W, H, px, gframe=1, spp_per_frame=S, max_depth=D, tmin=1e-3, tmax=tmax,
+                                    seed=0, return_rays=True)
+        return px.size, rays, time.perf_counter() - t
+
+    n, rays, dt = sample(a.cpu_sample_pixels or 2048)
+    if dt < 0.5 * budget_s and n < W * H:
+        n, rays, dt = sample(int(n * budget_s / max(dt, 1e-3)))
+    return {"value": round(rays / dt / 1e6, 4), "unit": "Mrays/s", "cores": O.max_threads(), "kind": "port",
+            "sample": f"{n} random pixels of {W}x{H} (global frame 1) x {S} spp, depth {D}: {rays} rays in {dt:.2f} s; "
+                      f"oracle BVH2 built in {build_s:.2f} s (not timed)"
+                      + ("; no top-level structure in the oracle: every ray tests every instance's root box" if a.instances is not None else ""),
+            "samples_per_px_per_s": round(S * n / (W * H) / dt, 6)}
 
 
 if __name__ == "__main__":

@@ -281,16 +281,17 @@ class OracleScene:
         return image, int(rays)
 
     def render_pixels(self, view, proj, W, H, pixels, gframe=0, spp_per_frame=10, max_depth=20, tmin=1e-3, tmax=1e4,
-                      seed=0):
-        """Per-dispatch colour of the listed pixels (linear index y*W+x) for global frame `gframe`."""
+                      seed=0, return_rays=False):
+        """Per-dispatch colour of the listed pixels (linear index y*W+x) for global frame `gframe` (return_rays: and the
+        number of rays traced for them)."""
         px = np.ascontiguousarray(pixels, dtype=np.uint32)
         out = np.zeros((px.size, 3), dtype=np.float32)
         v = np.ascontiguousarray(view, dtype=np.float32)
         p = np.ascontiguousarray(proj, dtype=np.float32)
         pp = Params(spp_per_frame, max_depth, tmin, tmax, seed)
-        lib().pto_render_pixels(C.byref(self.c), self.bvh, _p(v), _p(p), W, H, C.byref(pp), gframe, _p(px), px.size,
-                                _p(out))
-        return out
+        rays = lib().pto_render_pixels(C.byref(self.c), self.bvh, _p(v), _p(p), W, H, C.byref(pp), gframe, _p(px), px.size,
+                                       _p(out))
+        return (out, int(rays)) if return_rays else out
 
     def morton(self):
         n = self.n_tris

@@ -22,6 +22,17 @@ def global_frames(rank: int, world: int, frames_per_rank: int):
     return [first + k * stride for k in range(frames_per_rank)]
 
 
+def strong_frame_count(rank: int, world: int, total_frames: int) -> int:
+    """Strong scaling over sample streams: a FIXED total of `total_frames` global frames (BASELINE configs[1]: 1024 spp)
+    is split across the ranks by the same rule -- rank r renders the global frames r, r+G, ... below the total -- so the
+    ranks' counts differ by at most one and their union is exactly 0 .. total_frames-1, whatever `world`."""
+    if not (0 <= rank < world):
+        raise ValueError(f"rank {rank} outside world of {world}")
+    if total_frames < 0:
+        raise ValueError("negative frame count")
+    return len(range(rank, total_frames, world))
+
+
 def tile_schedule(rank: int, world: int, width: int, height: int):
     """Image-tile split: rank r renders the r-th of `world` column strips,
     (x0, y0, w, h) for pt_set_tile.  Strip widths differ by at most one pixel; every rank renders the SAME

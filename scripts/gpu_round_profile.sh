@@ -22,7 +22,8 @@ timeout -s KILL 90 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_fe
 timeout -s KILL 90 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/pmc_write -- $B > $OUT/pmc_write.log 2>&1 || { tail $OUT/pmc_write.log; exit 1; }
 timeout -s KILL 90 rocprofv3 --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_WAVE_CYCLES SQ_BUSY_CYCLES --output-format csv -d $OUT/pmc_sq1 -- $B > $OUT/pmc_sq1.log 2>&1 || { tail $OUT/pmc_sq1.log; exit 1; }
 timeout -s KILL 90 rocprofv3 --pmc SQ_ACTIVE_INST_VALU SQ_THREAD_CYCLES_VALU SQ_ACTIVE_INST_ANY SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT SQ_WAVE_CYCLES GRBM_GUI_ACTIVE --output-format csv -d $OUT/pmc_sq2 -- $B > $OUT/pmc_sq2.log 2>&1 || { tail $OUT/pmc_sq2.log; exit 1; }
+timeout -s KILL 90 rocprofv3 --pmc TCC_HIT_sum TCC_MISS_sum TCC_REQ_sum --output-format csv -d $OUT/pmc_tcc -- $B > $OUT/pmc_tcc.log 2>&1 || { tail $OUT/pmc_tcc.log; exit 1; }
 cd $R
-for p in pmc_fetch pmc_write pmc_sq1 pmc_sq2; do python scripts/pmc_summary.py $OUT/$p | grep -E "k_paths" ; done > $OUT/pmc_summary.log
+for p in pmc_fetch pmc_write pmc_sq1 pmc_sq2 pmc_tcc; do python scripts/pmc_summary.py $OUT/$p | grep -E "k_paths" ; done > $OUT/pmc_summary.log
 cat $OUT/pmc_summary.log | cut -c1-400
 find $OUT/stats -name "*kernel_stats.csv" | head -1 | xargs cat | cut -c1-140

@@ -121,3 +121,54 @@ def test_two_rank_tile_split_equals_single_process_render(tmp_path, O, ocornell)
     ref[..., :3] /= float(frames)
     ref[..., 3] = 1.0
     assert np.array_equal(got.view(np.uint32), ref.view(np.uint32))
+
+
+# ---------------------------------------------------------------- strong scaling: a fixed total of frames ----
+def _strong_worker(rank, world, port, total_frames, out_path):
+    import sys
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), OMP_NUM_THREADS="2")
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import oracle as O
+    import pathtracer_amd as pa
+    from pathtracer_amd import multigpu
+    sc = pa.scenes.cornell_box()
+    osc = O.OracleScene(sc.vertices, sc.indices, sc.materials, sc.mat_indices)
+    W, H = 32, 24
+    view, proj = O.reference_camera(W, H)
+    first, stride = multigpu.frame_schedule(rank, world)
+    n = multigpu.strong_frame_count(rank, world, total_frames)  # what bench.py --scaling strong renders on this rank
+    img, _ = osc.render(view, proj, W, H, frames=n, spp_per_frame=4, max_depth=6, seed=11, first_frame=first,
+                        frame_stride=stride, accum_sum=True, nthreads=2)
+    t = torch.from_numpy(img)
+    multigpu.reduce_sum_image(t, dist, dst=0)
+    if rank == 0:
+        np.save(out_path, multigpu.finalize_mean(t.numpy(), total_frames))
+    dist.destroy_process_group()
+
+
+def test_strong_frame_count_partitions_a_fixed_total():
+    from pathtracer_amd import multigpu
+    for world in (1, 2, 3, 4, 8):
+        for total in (0, 1, 5, 7, 8, 64, 1024):
+            counts = [multigpu.strong_frame_count(r, world, total) for r in range(world)]
+            assert sum(counts) == total and max(counts) - min(counts) <= 1
+            frames = sorted(f for r in range(world) for f in multigpu.global_frames(r, world, counts[r]))
+            assert frames == list(range(total))
+    with pytest.raises(ValueError):
+        multigpu.strong_frame_count(3, 3, 10)
+
+
+def test_two_rank_strong_split_of_an_odd_total_equals_single_process_render(tmp_path, O, ocornell):
+    """5 frames over 2 ranks (3 + 2): the reduced image is the 5-frame render up to fp32 summation order."""
+    world, total = 2, 5
+    out = str(tmp_path / "strong.npy")
+    mp.spawn(_strong_worker, args=(world, _free_port(), total, out), nprocs=world, join=True)
+    got = np.load(out)
+    W, H = 32, 24
+    view, proj = O.reference_camera(W, H)
+    ref, _ = ocornell.render(view, proj, W, H, frames=total, spp_per_frame=4, max_depth=6, seed=11, accum_sum=True)
+    ref[..., :3] /= float(total)
+    assert np.allclose(got, ref, rtol=2e-6, atol=1e-6)
+    assert np.all(got[..., 3] == 1.0)
