@@ -72,14 +72,31 @@ constexpr int kDoneRingFull = PT_DONE_RING;  // >= 64 entries; below 127 a retir
 #define PT_DONE_RING_TINY 112
 #endif
 #ifndef PT_INST_RING
-#define PT_INST_RING 96
+#define PT_INST_RING 80
 #endif
 #ifndef PT_INST_VOTE3
 #define PT_INST_VOTE3 0
 #endif
 #ifndef PT_INST_STACK
-#define PT_INST_STACK 12
+#define PT_INST_STACK 10
 #endif
+// two-level scenes, A/B switches (profiles/r03b..r03f_ab*.log):
+//   PT_INST_EXIT_HEAD   a lane that pops PT_INSTANCE_END leaves the instance at the head of the next iteration (restore + pop)
+//                       instead of spending a leaf step of its own on it: teapot grid +9.4 %
+//   PT_INST_ENTRY_HEAD  K > 0: lanes at a top-level leaf enter their instance at the head of the iteration as soon as K of them
+//                       wait (and then take part in the vote as lanes at the bottom-level root); 0: inside the leaf step.
+//                       Measured K = 1 / 4 / 8 / 16: -11 % / -5 % / -2 % / -2 % -- the entry program (transform + ray
+//                       preparation, ~130 instructions) is too long to run for a handful of lanes in every iteration
+// LDS: a stack of 10 and a done ring of 80 entries make the kernel's 10 176 B fit 16 times into a CU (+4.6 % against 12 / 96
+// = 14 waves, once the exit no longer costs a leaf step; before that the same squeeze measured within noise)
+#ifndef PT_INST_EXIT_HEAD
+#define PT_INST_EXIT_HEAD 1
+#endif
+#ifndef PT_INST_ENTRY_HEAD
+#define PT_INST_ENTRY_HEAD 0
+#endif
+constexpr bool kInstExitHead = PT_INST_EXIT_HEAD != 0;
+constexpr uint32_t kInstEntryHead = PT_INST_ENTRY_HEAD;
 constexpr int kDoneRingInst = PT_INST_RING;  // two-level scenes: their 1.8 KB of saved world rays cost occupancy otherwise
 constexpr int kStackLdsInst = PT_INST_STACK;
 constexpr bool kInstVote3 = PT_INST_VOTE3 != 0;
@@ -631,9 +648,79 @@ __global__ void __launch_bounds__(PT_WAVE) PT_PATHS_OCCUPANCY k_paths(PtPathsArg
 		return popcWave(mm);
 	};
 
+	// two-level scenes: the bottom-level traversal of the lane's instance is finished -- back to the world ray and on with
+	// whatever the top-level traversal left on the stack
+	auto leaveInstance = [&]() {
+		ox = wox;
+		oy = woy;
+		oz = woz;
+		ix = __uint_as_float(sSave[0][lane]);
+		iy = __uint_as_float(sSave[1][lane]);
+		iz = __uint_as_float(sSave[2][lane]);
+		Sx = __uint_as_float(sSave[3][lane]);
+		Sy = __uint_as_float(sSave[4][lane]);
+		Sz = __uint_as_float(sSave[5][lane]);
+		kpack = sSave[6][lane];
+		inst = PT_NO_INSTANCE;
+		cur = pt_stack_pop<kStackLds>(sp, sStack, lane, mySpill, a.spillStride);
+	};
+
+	// top-level leaf = instance: ray into object space, o' = W2O * (o,1), d' = W2O * (d,0), each row
+	// ((m0*x + m1*y) + m2*z) + m3 -- then the same preparation as in the staging phase
+	struct InstLoads
+	{
+		float4 r0, r1, r2;
+		uint32_t root;
+	};
+	auto loadInstance = [&](InstLoads &L) {
+		const uint32_t i = cur & 0x0FFFFFFFu;
+		const float4 *w = reinterpret_cast<const float4 *>(a.instances + 24 * (size_t)i + 12);
+		L.r0 = w[0];
+		L.r1 = w[1];
+		L.r2 = w[2];
+		L.root = a.instRoot[i];  // root of the bottom-level tree of the instance's Model
+	};
+	auto enterInstance = [&](const InstLoads &L) {
+		inst = cur & 0x0FFFFFFFu;
+		const float4 r0 = L.r0, r1 = L.r1, r2 = L.r2;
+		float3x oo, od;
+		oo.x = ((r0.x * wox + r0.y * woy) + r0.z * woz) + r0.w;
+		oo.y = ((r1.x * wox + r1.y * woy) + r1.z * woz) + r1.w;
+		oo.z = ((r2.x * wox + r2.y * woy) + r2.z * woz) + r2.w;
+		od.x = (r0.x * wdx + r0.y * wdy) + r0.z * wdz;
+		od.y = (r1.x * wdx + r1.y * wdy) + r1.z * wdz;
+		od.z = (r2.x * wdx + r2.y * wdy) + r2.z * wdz;
+		sSave[0][lane] = __float_as_uint(ix);
+		sSave[1][lane] = __float_as_uint(iy);
+		sSave[2][lane] = __float_as_uint(iz);
+		sSave[3][lane] = __float_as_uint(Sx);
+		sSave[4][lane] = __float_as_uint(Sy);
+		sSave[5][lane] = __float_as_uint(Sz);
+		sSave[6][lane] = kpack;
+		const PtLaneRay pr = pt_prepare_ray(oo, od);
+		ox = pr.ox;
+		oy = pr.oy;
+		oz = pr.oz;
+		ix = pr.ix;
+		iy = pr.iy;
+		iz = pr.iz;
+		Sx = pr.Sx;
+		Sy = pr.Sy;
+		Sz = pr.Sz;
+		kpack = pr.kpack | (kpack & 0xFFFF0000u);  // keep the depth bits
+		pt_stack_push<kStackLds>(PT_INSTANCE_END, sp, sStack, lane, mySpill, a.spillStride);
+		cur = L.root;
+		if (kStats) ++leafVisits;
+	};
+	static_assert(!kInstEntryHead || kInstExitHead, "entry at the head of the iteration: the exit too");
+
 	for (;;)
 	{
 		PT_T_MARK(PT_T_LOOP)
+		if (kInst && kInstExitHead && __ballot(cur == PT_INSTANCE_END))
+		{
+			if (cur == PT_INSTANCE_END) leaveInstance();
+		}
 		if (kEntry && !kFlat && cur == PT_TRAVERSAL_DONE && pend != 0u)
 		{
 			// the subtree of one entry child is finished (the sentinel was popped): on to the next child the ray hits
@@ -970,8 +1057,26 @@ __global__ void __launch_bounds__(PT_WAVE) PT_PATHS_OCCUPANCY k_paths(PtPathsArg
 		}
 		// One step for the LARGER of the two groups (majority-phase stepping, see pt_bounce.hip).
 		PT_T_MARK(PT_T_LOOP)
+		bool waitsForEntry = false;
+		if (kInst && kInstEntryHead)
+		{
+			// lanes at a top-level leaf (reference = PT_LEAF_FLAG | instance) enter their instance now -- all that wait, as soon as
+			// K wait or no other lane has anything else to do -- and are lanes at a node (the bottom-level root) in the vote
+			waitsForEntry = inst == PT_NO_INSTANCE && (cur & PT_LEAF_FLAG) && cur < PT_INSTANCE_END;
+			const unsigned long long wm = __ballot(waitsForEntry);
+			if (wm && (popcWave(wm) >= kInstEntryHead || !__ballot(!waitsForEntry && cur != PT_TRAVERSAL_DONE)))
+			{
+				if (waitsForEntry)
+				{
+					InstLoads L;
+					loadInstance(L);
+					enterInstance(L);
+				}
+				waitsForEntry = false;
+			}
+		}
 		const unsigned long long nodeLanes = __ballot(!(cur & PT_LEAF_FLAG));
-		const bool atLeaf = (cur & PT_LEAF_FLAG) && cur != PT_TRAVERSAL_DONE;
+		const bool atLeaf = (cur & PT_LEAF_FLAG) && cur != PT_TRAVERSAL_DONE && !waitsForEntry;
 		bool doNode, mine = atLeaf;  // mine: this lane belongs to the leaf group that steps
 		if (kInst && kInstVote3)
 		{
@@ -1003,60 +1108,15 @@ __global__ void __launch_bounds__(PT_WAVE) PT_PATHS_OCCUPANCY k_paths(PtPathsArg
 		}
 		if (!doNode && mine)
 		{
-			if (kInst && cur == PT_INSTANCE_END)
-			{
-				// bottom-level traversal finished: back to the world ray and the top-level tree
-				ox = wox;
-				oy = woy;
-				oz = woz;
-				ix = __uint_as_float(sSave[0][lane]);
-				iy = __uint_as_float(sSave[1][lane]);
-				iz = __uint_as_float(sSave[2][lane]);
-				Sx = __uint_as_float(sSave[3][lane]);
-				Sy = __uint_as_float(sSave[4][lane]);
-				Sz = __uint_as_float(sSave[5][lane]);
-				kpack = sSave[6][lane];
-				inst = PT_NO_INSTANCE;
-				cur = pt_stack_pop<kStackLds>(sp, sStack, lane, mySpill, a.spillStride);
-			}
-			else if (kInst && inst == PT_NO_INSTANCE)
+			if (kInst && !kInstExitHead && cur == PT_INSTANCE_END) leaveInstance();
+			else if (kInst && !kInstEntryHead && inst == PT_NO_INSTANCE)
 			{
 				if (cur == PT_EMPTY_CHILD) cur = pt_stack_pop<kStackLds>(sp, sStack, lane, mySpill, a.spillStride);
 				else
 				{
-					// top-level leaf = instance: ray into object space, o' = W2O * (o,1), d' = W2O * (d,0), each row
-					// ((m0*x + m1*y) + m2*z) + m3 -- then the same preparation as in the staging phase
-					inst = cur & 0x0FFFFFFFu;
-					const float4 *w = reinterpret_cast<const float4 *>(a.instances + 24 * (size_t)inst + 12);
-					const float4 r0 = w[0], r1 = w[1], r2 = w[2];
-					float3x oo, od;
-					oo.x = ((r0.x * wox + r0.y * woy) + r0.z * woz) + r0.w;
-					oo.y = ((r1.x * wox + r1.y * woy) + r1.z * woz) + r1.w;
-					oo.z = ((r2.x * wox + r2.y * woy) + r2.z * woz) + r2.w;
-					od.x = (r0.x * wdx + r0.y * wdy) + r0.z * wdz;
-					od.y = (r1.x * wdx + r1.y * wdy) + r1.z * wdz;
-					od.z = (r2.x * wdx + r2.y * wdy) + r2.z * wdz;
-					sSave[0][lane] = __float_as_uint(ix);
-					sSave[1][lane] = __float_as_uint(iy);
-					sSave[2][lane] = __float_as_uint(iz);
-					sSave[3][lane] = __float_as_uint(Sx);
-					sSave[4][lane] = __float_as_uint(Sy);
-					sSave[5][lane] = __float_as_uint(Sz);
-					sSave[6][lane] = kpack;
-					const PtLaneRay pr = pt_prepare_ray(oo, od);
-					ox = pr.ox;
-					oy = pr.oy;
-					oz = pr.oz;
-					ix = pr.ix;
-					iy = pr.iy;
-					iz = pr.iz;
-					Sx = pr.Sx;
-					Sy = pr.Sy;
-					Sz = pr.Sz;
-					kpack = pr.kpack | (kpack & 0xFFFF0000u);  // keep the depth bits
-					pt_stack_push<kStackLds>(PT_INSTANCE_END, sp, sStack, lane, mySpill, a.spillStride);
-					cur = a.instRoot[inst];  // root of the bottom-level tree of the instance's Model
-					if (kStats) ++leafVisits;
+					InstLoads L;
+					loadInstance(L);
+					enterInstance(L);
 				}
 			}
 			else
