@@ -244,7 +244,14 @@ int pt_render_frames(pt_ctx *ctx, int n);
  * * 64 * spp_per_frame <= 2^18 paths per frame (e.g. 512 x 512 x 1 spp, 256 x 256 x 4 spp; larger images tile by tile with
  * pt_set_tile), spp_per_frame <= 256.  PT_PROFILE_KERNELS is ignored.  All contexts of one GPU share that GPU's array:
  * calls that overlap on one GPU (two streams, two host threads) race; calls that follow each other, from any context,
- * do not depend on what the previous one left behind. */
+ * do not depend on what the previous one left behind.  The grid is 1 024 waves (4 per CU, a quarter of pt_render_frames'
+ * occupancy: the rings of more do not fit the array), so the call is slower per frame than pt_render_frames.
+ * Under stream capture (pt_set_stream + hipStreamBeginCapture; verified in global capture mode,
+ * tests/test_zz_no_alloc.py::test_noalloc_under_hip_graph_capture): the call records five kernel launches per batch of
+ * frames and nothing else.  Frame numbers, seed words and the accumulation position are kernel ARGUMENTS computed from
+ * the context's frame counter when the call is RECORDED (the counter advances then, not at replay): a graph replays
+ * exactly the frames it recorded -- it is not a progressive loop.  To accumulate with graphs, record one call per launch
+ * position (graph k renders frames kn .. kn+n-1 and continues the image graph k-1 left) and launch them in order. */
 int pt_render_frames_noalloc(pt_ctx *ctx, int n);
 
 /* VulkanRaytracing::resetFrame (VulkanRaytracing.cpp:910-913): frame = -1. */

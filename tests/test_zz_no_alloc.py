@@ -83,3 +83,134 @@ def test_noalloc_tiles_and_limits(pa, cornell):
     rt.setTile(0, 0, 8, 8)
     assert L.pt_render_frames_noalloc(rt._ctx, 1) == -5
     rt.cleanup()
+
+
+# ------------------------------------------------------------------------------------------------------------------------
+# The property the entry point exists for, checked directly: nothing is allocated, and it can be recorded into a HIP graph.
+def _hip():
+    import ctypes as C
+    hip = C.CDLL("libamdhip64.so")
+    for name in ("hipStreamCreate", "hipStreamDestroy", "hipStreamSynchronize", "hipStreamBeginCapture", "hipStreamEndCapture",
+                 "hipGraphInstantiate", "hipGraphLaunch", "hipGraphExecDestroy", "hipGraphDestroy", "hipMemGetInfo",
+                 "hipDeviceSynchronize"):
+        getattr(hip, name).restype = C.c_int
+    hip.hipStreamBeginCapture.argtypes = [C.c_void_p, C.c_int]
+    hip.hipStreamEndCapture.argtypes = [C.c_void_p, C.POINTER(C.c_void_p)]
+    hip.hipGraphInstantiate.argtypes = [C.POINTER(C.c_void_p), C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t]
+    hip.hipGraphLaunch.argtypes = [C.c_void_p, C.c_void_p]
+    hip.hipStreamCreate.argtypes = [C.POINTER(C.c_void_p)]
+    for name in ("hipStreamDestroy", "hipStreamSynchronize", "hipGraphExecDestroy", "hipGraphDestroy"):
+        getattr(hip, name).argtypes = [C.c_void_p]
+    hip.hipMemGetInfo.argtypes = [C.POINTER(C.c_size_t), C.POINTER(C.c_size_t)]
+    return hip
+
+
+def _free_bytes(hip):
+    import ctypes as C
+    f, t = C.c_size_t(), C.c_size_t()
+    assert hip.hipDeviceSynchronize() == 0 and hip.hipMemGetInfo(C.byref(f), C.byref(t)) == 0
+    return f.value
+
+
+def _setup(pa, scene, W, H, spp, depth, seed, instances=None):
+    rt = pa.HipRaytracing(0)
+    view, proj = pa.reference_camera(W, H)
+    if instances is not None:
+        rt.uploadScene(scene)
+        rt.setInstances(instances)
+        rt.buildBlas()
+    else:
+        rt.buildBlas(scene)
+    rt.buildTlas()
+    rt.resize(W, H)
+    rt.setCamera(view, proj)
+    rt.setParams(spp_per_frame=spp, max_depth=depth, seed=seed, max_frames=0)
+    return rt
+
+
+def _three_boxes():
+    """object-to-world 3x4 of three Cornell boxes: shifted, rotated about y and scaled, mirrored"""
+    import math
+    c, s = math.cos(0.6), math.sin(0.6)
+    return np.array([[1, 0, 0, -1.2, 0, 1, 0, 0, 0, 0, 1, -1.0],
+                     [0.7 * c, 0, 0.7 * s, 1.1, 0, 0.8, 0, 0.1, -0.7 * s, 0, 0.7 * c, -1.5],
+                     [-1, 0, 0, 0.2, 0, 1, 0, 1.9, 0, 0, 1, -3.0]], dtype=np.float32)
+
+
+def test_noalloc_allocates_nothing_and_mixes_with_render_frames(pa, cornell):
+    """Device memory free before == free after a pt_render_frames_noalloc call (hipMemGetInfo), on a single-level and on a
+    two-level scene, also on a context whose pt_render_frames buffers already exist; and the two entry points interleaved on ONE
+    context continue each other's accumulation exactly (image and ray count of raytrace, noalloc, raytrace == one raytrace)."""
+    hip = _hip()
+    for instances in (None, _three_boxes()):
+        W, H, spp, depth = 160, 120, 3, 6
+        rt = _setup(pa, cornell, W, H, spp, depth, 7, instances)
+        rt.raytraceNoAlloc(1)  # (the first launch of a kernel loads its code object: not the entry point's allocation)
+        rt.raytrace(2)         # pt_render_frames creates its own buffers: they must be neither used nor grown below
+        rt.resetFrame()
+        rt.resetStats()
+        before = _free_bytes(hip)
+        rt.raytraceNoAlloc(3)
+        rt.raytraceNoAlloc(1)
+        assert _free_bytes(hip) == before
+        rt.raytrace(2)
+        rt.raytraceNoAlloc(2)
+        got, rays = rt.readImage(), rt.stats().rays_total
+        rt.cleanup()
+        ref = _setup(pa, cornell, W, H, spp, depth, 7, instances)
+        ref.raytrace(8)
+        want, wrays = ref.readImage(), ref.stats().rays_total
+        ref.cleanup()
+        assert rays == wrays and np.array_equal(bits(got), bits(want)) and got[..., :3].max() > 0
+
+
+def test_noalloc_under_hip_graph_capture(pa, cornell):
+    """pt_render_frames_noalloc recorded between hipStreamBeginCapture / hipStreamEndCapture (global mode: any call that is
+    not allowed under capture fails it) on a caller's stream, instantiated and launched.  The frame numbers and seed words
+    are kernel ARGUMENTS, fixed when the call is recorded: a graph replays exactly the frames it recorded -- launching the
+    first graph (frames 0 .. F-1, which overwrite the image) twice leaves the image of F frames; a second graph recorded
+    after it continues the accumulation with frames F .. 2F-1.  Both bit-identical to pt_render_frames."""
+    import ctypes as C
+    from pathtracer_amd import _lib
+    L = _lib.lib()
+    hip = _hip()
+    W, H, spp, depth, F = 200, 150, 4, 8, 3
+    rt = _setup(pa, cornell, W, H, spp, depth, 2)
+    rt.raytraceNoAlloc(1)  # code objects loaded, scratch address known: nothing left to initialise under capture
+    rt.resetFrame()
+    rt.resetStats()
+    stream = C.c_void_p()
+    assert hip.hipStreamCreate(C.byref(stream)) == 0
+    rt.set_stream(stream.value)
+    graphs, execs = [], []
+    for k in range(2):
+        assert hip.hipStreamBeginCapture(stream, 0) == 0  # hipStreamCaptureModeGlobal
+        rc = L.pt_render_frames_noalloc(rt._ctx, F)
+        g = C.c_void_p()
+        assert hip.hipStreamEndCapture(stream, C.byref(g)) == 0 and g.value
+        assert rc == 0, L.pt_last_error(rt._ctx).decode()
+        e = C.c_void_p()
+        assert hip.hipGraphInstantiate(C.byref(e), g, None, None, 0) == 0 and e.value
+        graphs.append(g)
+        execs.append(e)
+    assert rt.frame == 2 * F - 1  # the host-side counter advanced when the calls were recorded
+    ref = _setup(pa, cornell, W, H, spp, depth, 2)
+    ref.raytrace(F)
+    want1 = ref.readImage()
+    ref.raytrace(F)
+    want2 = ref.readImage()
+    ref.cleanup()
+    assert hip.hipGraphLaunch(execs[0], stream) == 0 and hip.hipStreamSynchronize(stream) == 0
+    got = rt.readImage()
+    assert np.array_equal(bits(got), bits(want1)) and got[..., :3].max() > 0
+    assert hip.hipGraphLaunch(execs[0], stream) == 0 and hip.hipStreamSynchronize(stream) == 0
+    assert np.array_equal(bits(rt.readImage()), bits(want1))  # a replay renders the same frames again
+    assert hip.hipGraphLaunch(execs[1], stream) == 0 and hip.hipStreamSynchronize(stream) == 0
+    assert np.array_equal(bits(rt.readImage()), bits(want2))
+    for e in execs:
+        hip.hipGraphExecDestroy(e)
+    for g in graphs:
+        hip.hipGraphDestroy(g)
+    rt.set_stream(None)
+    hip.hipStreamDestroy(stream)
+    rt.cleanup()
