@@ -266,6 +266,9 @@ int pt_read_image(pt_ctx *ctx, float *rgba32f);
 int pt_image_device_ptr(pt_ctx *ctx, void **dev_ptr);
 /* Overwrites the accumulation image from device memory (e.g. a reduced multi-GPU result). */
 int pt_write_image_from_device(pt_ctx *ctx, const void *dev_rgba32f);
+/* The same from host memory, the counterpart of pt_read_image (m_colorImage, main.cpp:908-931, is device-only in the
+ * reference): pt_render writes the mean of G GPUs' sums back so that the sRGB encode is the library's.  Synchronises. */
+int pt_write_image(pt_ctx *ctx, const float *rgba32f);
 
 /* Accumulation checkpoint: the RGBA32F image plus everything the frame counter's meaning depends on (frame
  * index, extent, sampling parameters, seed, frame schedule, accumulation mode).  The reference keeps this

@@ -70,6 +70,7 @@ SYMBOLS = {
     "pt_read_image": (_i, [_vp, _vp]),
     "pt_image_device_ptr": (_i, [_vp, C.POINTER(_vp)]),
     "pt_write_image_from_device": (_i, [_vp, _vp]),
+    "pt_write_image": (_i, [_vp, _vp]),
     "pt_read_image_srgb8": (_i, [_vp, _vp]),
     "pt_set_profiling": (_i, [_vp, _i]),
     "pt_get_stats": (_i, [_vp, C.POINTER(PtStats)]),

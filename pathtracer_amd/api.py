@@ -356,6 +356,13 @@ class HipRaytracing:
     def writeImageFromDevice(self, dev_ptr: int):
         self._check(self._L.pt_write_image_from_device(self._ctx, C.c_void_p(dev_ptr)))
 
+    def writeImage(self, rgba32f):
+        """Overwrites the accumulation image from host memory (pt_write_image): H x W x 4 float32."""
+        a = np.ascontiguousarray(rgba32f, dtype=np.float32)
+        if a.size != 4 * self.width * self.height:
+            raise ValueError("writeImage: expected H x W x 4 floats")
+        self._check(self._L.pt_write_image(self._ctx, _p(a)))
+
     def saveCheckpoint(self, path: str):
         """Accumulation image + frame index + sampling parameters (pt_save_checkpoint)."""
         self._check(self._L.pt_save_checkpoint(self._ctx, os.fsencode(path)))

@@ -1445,6 +1445,16 @@ extern "C" int pt_write_image_from_device(pt_ctx *c, const void *src)
 	return PT_OK;
 }
 
+extern "C" int pt_write_image(pt_ctx *c, const float *rgba)
+{
+	if (!c || !rgba) return fail(c, PT_EINVAL, "pt_write_image: null argument");
+	if (!c->image) return fail(c, PT_EINVAL, "pt_write_image: no image (pt_resize)");
+	PT_HIP(c, hipSetDevice(c->device));
+	PT_HIP(c, hipMemcpyAsync(c->image, rgba, sizeof(float4) * (size_t)c->W * c->H, hipMemcpyHostToDevice, c->stream));
+	PT_HIP(c, hipStreamSynchronize(c->stream));  // the caller's buffer is free to go when the call returns
+	return PT_OK;
+}
+
 // ---- accumulation checkpoint ----
 namespace
 {

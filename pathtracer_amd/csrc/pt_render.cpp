@@ -4,14 +4,20 @@
 //
 //   pt_render scene.obj [-w 800] [-h 600] [-spp 10] [-frames 100] [-depth 20] [-seed 0] [-tex map.png]
 //             (default: the first map_Kd of the OBJ's MTL file; `-tex none` renders untextured)
-//             [-o out.pfm|out.ppm|out.png] [-gpus G] [-devices 0,1,..] [-split streams|tiles]
+//             [-o out.pfm|out.ppm|out.png] [-gpus G] [-devices 0,1,..] [-split streams|tiles] [-reduce rccl|host]
 //
 // Defaults are the reference's constants (VulkanUtils.h:11-15, raytrace.rgen:22-23).
 // -gpus G: one host thread and one context per GPU (the rule of pathtracer_amd/multigpu.py): with
 // `streams` GPU r renders the global frames r, r+G, ... (frames rounded up to a multiple of G), with `tiles` every GPU renders
-// all frames of its own column strip; each accumulates raw sums (PT_ACCUM_SUM) against its own copy of the scene and BVH, and
-// the host adds the G images in rank order and divides by the number of frames -- no exchange between the GPUs.  -devices
-// names the ordinals (default 0 .. G-1; the same ordinal may appear twice, which is how one GPU rehearses the path).
+// all frames of its own column strip; each accumulates raw sums (PT_ACCUM_SUM) against its own copy of the scene and BVH.
+// The G sum images are then combined on GPU 0:
+//   -reduce rccl (default for G > 1)  ONE ncclReduce(sum, fp32, 4*W*H, root 0) over xGMI on the images where they lie
+//                (pt_image_device_ptr), a communicator per GPU from ncclCommInitAll -- the only exchange between the GPUs;
+//   -reduce host                      the images are read back and added on the host in rank order.  Also the fall-back when
+//                RCCL cannot set the communicators up (e.g. the same ordinal named twice in -devices, which is how one
+//                GPU rehearses the G-context path: RCCL wants one rank per device).
+// Then the mean over all frames (host) and alpha back to 1.  -gpus 1 -reduce rccl runs the same code with one rank.
+// -devices names the ordinals (default 0 .. G-1).
 #include <chrono>
 #include <cmath>
 #include <cstdio>
@@ -20,6 +26,9 @@
 #include <string>
 #include <thread>
 #include <vector>
+
+#include <hip/hip_runtime_api.h>
+#include <rccl/rccl.h>
 
 #include "pt_hip.h"
 
@@ -46,27 +55,14 @@ struct Job
 	int accum = PT_ACCUM_MEAN;
 	int device = 0;
 	// results
+	pt_ctx *ctx = nullptr;  // kept open until the images are combined
 	std::vector<float> image;
 	PtStats stats = {};
 	double seconds = 0.0;
 	int rc = EXIT_SUCCESS;
 };
 
-// post.frag + sRGB attachment on the host (the library's k_srgb8 on an image that exists only here: the sum of G GPUs')
-static void linearToSrgb8(const float *rgba, size_t nPixels, uint8_t *out)
-{
-	for (size_t i = 0; i < 4 * nPixels; ++i)
-	{
-		float x = rgba[i];
-		if (!(x > 0.0f)) x = 0.0f;
-		if (x > 1.0f) x = 1.0f;
-		float e = x;
-		if ((i & 3) < 3) e = x <= 0.0031308f ? x * 12.92f : 1.055f * powf(x, 1.0f / 2.4f) - 0.055f;
-		out[i] = (uint8_t)(e * 255.0f + 0.5f);
-	}
-}
-
-// Everything one GPU does: context, scene, acceleration structure, frames, read-back.
+// Everything one GPU does up to the last frame: context, scene, acceleration structure, frames.  The context stays open.
 static int renderOn(Job &j)
 {
 	pt_ctx *ctx = pt_create(j.device);
@@ -101,10 +97,64 @@ static int renderOn(Job &j)
 	CHECK(pt_synchronize(ctx));
 	j.seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
 	CHECK(pt_get_stats(ctx, &j.stats));
-	j.image.resize(4 * (size_t)j.W * j.H);
-	CHECK(pt_read_image(ctx, j.image.data()));
-	pt_destroy(ctx);
+	j.ctx = ctx;
 	return EXIT_SUCCESS;
+}
+
+// ONE ncclReduce(sum) of the G accumulation images onto GPU 0, in place.  false: RCCL could not be set up
+// (the images are untouched; the caller adds them on the host).
+static bool reduceWithRccl(std::vector<Job> &jobs, size_t count, double *seconds)
+{
+	const int G = (int)jobs.size();
+	std::vector<int> devs((size_t)G);
+	for (int r = 0; r < G; ++r) devs[(size_t)r] = jobs[(size_t)r].device;
+	for (int a = 0; a < G; ++a)
+		for (int b = a + 1; b < G; ++b)
+			if (devs[(size_t)a] == devs[(size_t)b])
+			{
+				fprintf(stderr, "-reduce rccl: device %d named twice (RCCL wants one rank per device): adding on the host\n", devs[(size_t)a]);
+				return false;
+			}
+	std::vector<ncclComm_t> comms((size_t)G, nullptr);
+	ncclResult_t e = ncclCommInitAll(comms.data(), G, devs.data());
+	if (e != ncclSuccess)
+	{
+		fprintf(stderr, "-reduce rccl: ncclCommInitAll: %s: adding on the host\n", ncclGetErrorString(e));
+		return false;
+	}
+	std::vector<void *> img((size_t)G, nullptr);
+	bool ok = true;
+	for (int r = 0; r < G && ok; ++r) ok = pt_image_device_ptr(jobs[(size_t)r].ctx, &img[(size_t)r]) == PT_OK;
+	auto t0 = std::chrono::steady_clock::now();
+	if (ok)
+	{
+		// every context has been synchronised (renderOn): the reduce runs on each device's null stream
+		ncclGroupStart();
+		for (int r = 0; r < G; ++r)
+		{
+			hipSetDevice(devs[(size_t)r]);
+			e = ncclReduce(img[(size_t)r], img[(size_t)r], count, ncclFloat, ncclSum, 0, comms[(size_t)r], nullptr);
+			if (e != ncclSuccess) ok = false;
+		}
+		e = ncclGroupEnd();
+		if (e != ncclSuccess) ok = false;
+		for (int r = 0; r < G; ++r)
+		{
+			hipSetDevice(devs[(size_t)r]);
+			if (hipStreamSynchronize(nullptr) != hipSuccess) ok = false;
+		}
+		if (!ok) fprintf(stderr, "-reduce rccl: ncclReduce failed: %s\n", ncclGetErrorString(e));
+	}
+	*seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+	for (ncclComm_t c : comms)
+		if (c) ncclCommDestroy(c);
+	if (!ok)
+	{
+		// a failed collective may have left partial sums behind: nothing to fall back to
+		fprintf(stderr, "-reduce rccl: the images are not usable after a failed collective\n");
+		exit(EXIT_FAILURE);
+	}
+	return true;
 }
 
 int main(int argc, char **argv)
@@ -112,10 +162,10 @@ int main(int argc, char **argv)
 	pt_ctx *ctx = nullptr;
 	if (argc < 2)
 	{
-		fprintf(stderr, "usage: %s scene.obj [-w W] [-h H] [-spp S] [-frames F] [-depth D] [-seed X] [-tex map.png] [-o out.pfm|.ppm|.png] [-gpus G] [-devices a,b,..] [-split streams|tiles]\n", argv[0]);
+		fprintf(stderr, "usage: %s scene.obj [-w W] [-h H] [-spp S] [-frames F] [-depth D] [-seed X] [-tex map.png] [-o out.pfm|.ppm|.png] [-gpus G] [-devices a,b,..] [-split streams|tiles] [-reduce rccl|host]\n", argv[0]);
 		return EXIT_FAILURE;
 	}
-	std::string objPath = argv[1], out = "out.pfm", split = "streams";
+	std::string objPath = argv[1], out = "out.pfm", split = "streams", reduce = "";
 	Job base;
 	int gpus = 1;
 	std::vector<int> devices;
@@ -133,6 +183,7 @@ int main(int argc, char **argv)
 		else if (k == "-tex") base.texPath = v;
 		else if (k == "-gpus") gpus = atoi(v);
 		else if (k == "-split") split = v;
+		else if (k == "-reduce") reduce = v;
 		else if (k == "-devices")
 		{
 			for (const char *p = v; *p;)
@@ -149,9 +200,9 @@ int main(int argc, char **argv)
 		}
 	}
 	if (gpus < 1 || (split != "streams" && split != "tiles") || (!devices.empty() && (int)devices.size() != gpus) ||
-	    (split == "tiles" && (uint32_t)gpus > base.W) || base.frames < 1)
+	    (split == "tiles" && (uint32_t)gpus > base.W) || base.frames < 1 || (!reduce.empty() && reduce != "rccl" && reduce != "host"))
 	{
-		fprintf(stderr, "bad -gpus / -devices / -split / -frames\n");
+		fprintf(stderr, "bad -gpus / -devices / -split / -frames / -reduce\n");
 		return EXIT_FAILURE;
 	}
 	PtSceneData *sd = nullptr;
@@ -182,7 +233,7 @@ int main(int argc, char **argv)
 		Job &j = jobs[(size_t)r];
 		j.device = devices.empty() ? r : devices[(size_t)r];
 		j.frames = perGpu;
-		if (gpus > 1)
+		if (gpus > 1 || reduce == "rccl")
 		{
 			j.accum = PT_ACCUM_SUM;
 			if (tiles)
@@ -208,22 +259,42 @@ int main(int argc, char **argv)
 		for (int r = 0; r < gpus; ++r) th.emplace_back([&jobs, r] { jobs[(size_t)r].rc = renderOn(jobs[(size_t)r]); });
 		for (std::thread &t : th) t.join();
 	}
-	const double sec = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
 	for (const Job &j : jobs)
 		if (j.rc != EXIT_SUCCESS) return j.rc;
-	std::vector<float> &img = jobs[0].image;
-	double renderSec = jobs[0].seconds;
-	unsigned long long rays = jobs[0].stats.rays_total;
-	if (gpus > 1)
+	ctx = jobs[0].ctx;
+	const bool sums = gpus > 1 || reduce == "rccl";  // the contexts hold raw sums over their frames
+	double renderSec = 0.0, reduceSec = 0.0;
+	unsigned long long rays = 0;
+	for (const Job &j : jobs)
 	{
-		// the reduce(sum) of multigpu.py, in rank order, then the mean over all frames; alpha back to 1 (rgen:92)
-		for (int r = 1; r < gpus; ++r)
+		if (j.seconds > renderSec) renderSec = j.seconds;
+		rays += j.stats.rays_total;
+	}
+	const char *how = "one context";
+	std::vector<float> &img = jobs[0].image;
+	img.resize(4 * (size_t)W * H);
+	if (sums)
+	{
+		const bool viaRccl = reduce != "host" && reduceWithRccl(jobs, 4 * (size_t)W * H, &reduceSec);
+		how = viaRccl ? "RCCL reduce" : "host sum";
+		CHECK(pt_read_image(ctx, img.data()));
+		if (!viaRccl)
 		{
-			const std::vector<float> &o = jobs[(size_t)r].image;
-			for (size_t i = 0; i < img.size(); ++i) img[i] += o[i];
-			if (jobs[(size_t)r].seconds > renderSec) renderSec = jobs[(size_t)r].seconds;
-			rays += jobs[(size_t)r].stats.rays_total;
+			// the reduce(sum) of multigpu.py on the host, in rank order
+			auto h0 = std::chrono::steady_clock::now();
+			std::vector<float> o(img.size());
+			for (int r = 1; r < gpus; ++r)
+			{
+				if (pt_read_image(jobs[(size_t)r].ctx, o.data()) != PT_OK)
+				{
+					fprintf(stderr, "pt_read_image: %s\n", pt_last_error(jobs[(size_t)r].ctx));
+					return EXIT_FAILURE;
+				}
+				for (size_t i = 0; i < img.size(); ++i) img[i] += o[i];
+			}
+			reduceSec = std::chrono::duration<double>(std::chrono::steady_clock::now() - h0).count();
 		}
+		// the mean over all frames; alpha back to 1 (rgen:92)
 		const float n = (float)totalFrames;
 		for (size_t i = 0; i < img.size(); i += 4)
 		{
@@ -232,23 +303,28 @@ int main(int argc, char **argv)
 			img[i + 2] /= n;
 			img[i + 3] = 1.0f;
 		}
+		CHECK(pt_write_image(ctx, img.data()));  // GPU 0 holds the final image: the sRGB encode below is the library's
 	}
+	else CHECK(pt_read_image(ctx, img.data()));
+	const double sec = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
 	const PtStats &st = jobs[0].stats;
-	printf("%u triangles, BVH4 %u nodes (build %.3f ms); %d frames x %d spp at %ux%u on %d GPU%s (%s): %.3f s render (%.3f s with set-up), %.1f Mrays/s, %.2f spp/px/s\n",
-	       st.bvh_tris, st.bvh_nodes, st.build_ms, totalFrames, base.spp, W, H, gpus, gpus > 1 ? "s" : "", gpus > 1 ? split.c_str() : "one context",
-	       renderSec, sec, rays / renderSec / 1e6, totalFrames * base.spp / renderSec);
+	printf("%u triangles, BVH4 %u nodes (build %.3f ms); %d frames x %d spp at %ux%u on %d GPU%s (%s, %s): %.3f s render + %.4f s reduce (%.3f s with set-up), %.1f Mrays/s, %.2f spp/px/s\n",
+	       st.bvh_tris, st.bvh_nodes, st.build_ms, totalFrames, base.spp, W, H, gpus, gpus > 1 ? "s" : "", gpus > 1 ? split.c_str() : "streams", how,
+	       renderSec, reduceSec, sec, rays / (renderSec + reduceSec) / 1e6, totalFrames * base.spp / (renderSec + reduceSec));
 	if (st.accel_bytes_uncompacted)  // the reference's log line, VulkanRaytracing.cpp:254-255
 		printf("Reduced size of BLAS by %.1f%% from %llu to %llu\n", 100.0 * (double)(st.accel_bytes_uncompacted - st.accel_bytes) / (double)st.accel_bytes_uncompacted,
 		       (unsigned long long)st.accel_bytes_uncompacted, (unsigned long long)st.accel_bytes);
 	const std::string ext = out.size() > 4 ? out.substr(out.size() - 4) : "";
 	if (ext == ".ppm" || ext == ".png")
 	{
+		// post.frag + the sRGB attachment: the library's device-side encode, whatever the number of GPUs
 		std::vector<uint8_t> px(4 * (size_t)W * H);
-		linearToSrgb8(img.data(), (size_t)W * H, px.data());
+		CHECK(pt_read_image_srgb8(ctx, px.data()));
 		if (ext == ".png") CHECK(pt_write_png(out.c_str(), px.data(), W, H));
 		else CHECK(pt_write_ppm(out.c_str(), px.data(), W, H));
 	}
 	else CHECK(pt_write_pfm(out.c_str(), img.data(), W, H));
+	for (Job &j : jobs) pt_destroy(j.ctx);
 	pt_scene_free(sd);
 	return EXIT_SUCCESS;
 }

@@ -76,7 +76,7 @@ def test_pt_render_one_and_two_contexts(pa, tmp_path):
 
     out2 = str(tmp_path / "two.pfm")
     log = run(common + ["-gpus", "2", "-devices", "0,0", "-o", out2])
-    assert "on 2 GPUs (streams)" in log
+    assert "on 2 GPUs (streams, host sum)" in log  # one ordinal named twice: RCCL wants a rank per device, so the host adds
     acc = None
     for r in range(2):
         first, stride = multigpu.frame_schedule(r, 2)
@@ -94,6 +94,50 @@ def test_pt_render_one_and_two_contexts(pa, tmp_path):
     assert np.array_equal(bits(read_pfm(outp)), bits(want3[..., :3]))
     run(common + ["-gpus", "3", "-devices", "0,0,0", "-split", "tiles", "-o", out3])
     assert os.path.getsize(out3) > 100
+
+
+def test_pt_render_rccl_reduce_one_rank_and_device_side_srgb(pa, tmp_path):
+    """-reduce rccl with one rank: ncclCommInitAll + ncclReduce(sum, fp32, 4*W*H) on the image where it lies
+    (pt_image_device_ptr), then the mean -- the G > 1 code path with G = 1, which is all one GPU can run.  The image equals
+    the sum image of the API divided by the frame count.  And -o x.png is the LIBRARY's sRGB encode (pt_read_image_srgb8 on the
+    final image, whatever the number of GPUs): byte-identical to readImageSrgb8 of the same render."""
+    from pathtracer_amd import multigpu
+    obj = pa.scenes.write_cornell_box(str(tmp_path))
+    scene = pa.load_obj(obj)
+    W, H, spp, depth, seed, frames = 64, 48, 3, 6, 4, 5
+    common = [obj, "-w", str(W), "-h", str(H), "-spp", str(spp), "-depth", str(depth), "-seed", str(seed), "-frames", str(frames)]
+    out = str(tmp_path / "rccl.pfm")
+    log = run(common + ["-gpus", "1", "-reduce", "rccl", "-o", out])
+    assert "RCCL reduce" in log, log
+    whole, _ = api_sum(pa, scene, W, H, spp, depth, seed, frames)
+    want = multigpu.finalize_mean(whole.copy(), frames)
+    assert np.array_equal(bits(read_pfm(out)), bits(want[..., :3])) and want[..., :3].max() > 0
+    # -reduce host on the same job: the same image
+    outh = str(tmp_path / "host.pfm")
+    assert "host sum" in run(common + ["-gpus", "2", "-devices", "0,0", "-reduce", "host", "-o", outh])
+    # PNG of a one-context render == the library's device-side encode of the same image
+    png = str(tmp_path / "one.png")
+    run(common + ["-o", png])
+    rt = pa.HipRaytracing(0)
+    rt.buildBlas(scene)
+    rt.resize(W, H)
+    rt.setCamera(*pa.reference_camera(W, H))
+    rt.setParams(spp_per_frame=spp, max_depth=depth, seed=seed, max_frames=frames)
+    rt.raytrace(frames)
+    want8 = rt.readImageSrgb8()
+    # ... and of the G-context mean written back with pt_write_image
+    png2 = str(tmp_path / "two.png")
+    run(common + ["-gpus", "2", "-devices", "0,0", "-frames", "6", "-o", png2])
+    acc = None
+    for r in range(2):
+        first, stride = multigpu.frame_schedule(r, 2)
+        img, _ = api_sum(pa, scene, W, H, spp, depth, seed, 3, first, stride)
+        acc = img.copy() if acc is None else acc + img
+    rt.writeImage(multigpu.finalize_mean(acc, 6))
+    want8b = rt.readImageSrgb8()
+    rt.cleanup()
+    assert np.array_equal(pa.load_png(png).reshape(H, W, 4), want8.reshape(H, W, 4))
+    assert np.array_equal(pa.load_png(png2).reshape(H, W, 4), want8b.reshape(H, W, 4))
 
 
 def test_pt_render_loads_the_map_kd_of_the_mtl(pa, tmp_path):
@@ -142,6 +186,7 @@ def test_pt_render_loads_the_map_kd_of_the_mtl(pa, tmp_path):
 
 def test_pt_render_rejects_bad_arguments(tmp_path, pa):
     obj = pa.scenes.write_cornell_box(str(tmp_path))
-    for extra in (["-gpus", "0"], ["-gpus", "2", "-devices", "0"], ["-split", "rows"], ["-gpus", "1", "-devices", "99"]):
+    for extra in (["-gpus", "0"], ["-gpus", "2", "-devices", "0"], ["-split", "rows"], ["-gpus", "1", "-devices", "99"],
+                  ["-reduce", "mpi"]):
         r = subprocess.run([PT_RENDER, obj, "-w", "16", "-h", "16", "-frames", "1"] + extra, capture_output=True, text=True, timeout=120)
         assert r.returncode != 0, extra
