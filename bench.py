@@ -15,7 +15,9 @@ the environment) it starts `python -m torch.distributed.run --nproc-per-node N .
 child process BEFORE anything touches the GPU, relays rank 0's JSON line and exits with the child's code.
   --split streams (default; configs 2-4): rank r renders the global frames r, r+N, ... against a replicated
       scene/BVH into raw sums; one RCCL reduce(sum) of the image inside the timed region.  Weak scaling.
-  --split tiles (config 5): every rank renders the SAME frames on its own column strip; same reduce.  Strong scaling.
+  --split tiles (config 5): every rank renders the SAME frames on its own share of the image -- blocks of --tile-block
+      columns dealt round-robin (0: one column strip per rank); same reduce.  Strong scaling.
+  --scaling strong (with --split streams): --steps is the TOTAL number of frames, split across the ranks.
 
 Rank 0 prints ONE JSON line.  `roofline` prices the dominant kernel (k_paths) against the bound that binds it --
 VALU issue on the cache-resident Cornell box -- and `roofline_hbm` keeps the HBM figure: achieved = algorithmic
@@ -65,6 +67,10 @@ def parse(argv=None):
                          "configs[2] (viking_room.obj with a 1024^2 diffuse map, use --width 3840 --height 2160); teapot = configs[3] "
                          "(teapot.obj x 64x64 instances) -- both meshes from tests/golden/ref_seam.npz, one light quad added")
     ap.add_argument("--tris", type=float, default=1e6, help="--scene soup: number of triangles")
+    ap.add_argument("--tile-block", type=int, default=32,
+                    help="--split tiles: columns per block of the interleaved schedule (blocks dealt round-robin to the ranks: "
+                         "pt_set_tile_interleaved); 0 = one column strip per rank (max/mean strip time 2.1 on configs[4], "
+                         "profiles/r03j_tile_balance.log)")
     ap.add_argument("--scaling", choices=["weak", "strong"], default="weak",
                     help="--split streams only.  weak: every rank renders --steps frames (N x the samples).  strong: --steps is the "
                          "TOTAL number of frames (configs[1]: a fixed 1024 spp), rank r renders the global frames r, r+N, ... below it")
@@ -293,7 +299,10 @@ def main():
 
     if tiles:
         rt.setFrameSchedule(first=0, stride=1)  # every rank renders the same frames ...
-        rt.setTile(*multigpu.tile_schedule(rank, world, W, H))  # ... on its own column strip
+        if a.tile_block > 0:
+            rt.setTileInterleaved(rank, world, a.tile_block)  # ... on its own share of the column blocks
+        else:
+            rt.setTile(*multigpu.tile_schedule(rank, world, W, H))  # ... on its own column strip
     else:
         first, stride = multigpu.frame_schedule(rank, world)
         rt.setFrameSchedule(first=first, stride=stride)
@@ -471,7 +480,8 @@ def main():
                                    f"({a.builder.upper()})" + {"cornell": " (BASELINE.json configs[1])", "soup": " (BASELINE.json configs[4] generator)",
                                                              "viking": " (BASELINE.json configs[2])", "teapot": " (BASELINE.json configs[3])"}[a.scene],
                        "width": W, "height": H, "spp_per_frame": S, "max_depth": D, "total_spp": total_spp,
-                       "parallelism": (f"image tiles (column strips) x{world}" if tiles else
+                       "parallelism": ((f"image tiles (blocks of {a.tile_block} columns, round-robin) x{world}" if a.tile_block > 0
+                                        else f"image tiles (column strips) x{world}") if tiles else
                                        f"sample-stream x{world}" + (" (frames of one fixed total split across the ranks)" if strong else ""))},
             "samples_per_px_per_s": round(total_spp / dt_max, 3),
             "rays_per_step_per_gpu": rays_local / max(1, local_frames(a.steps)),

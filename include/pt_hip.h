@@ -213,6 +213,12 @@ int pt_image_extent(pt_ctx *ctx, uint32_t *width, uint32_t *height);
  * sample streams.  Every pixel's value is independent of the tiling (seeds use the full-image pixel index).
  * w = h = 0 restores the whole image; pt_resize does too. */
 int pt_set_tile(pt_ctx *ctx, uint32_t x0, uint32_t y0, uint32_t w, uint32_t h);
+/* The same split with the load spread evenly (no reference counterpart): the image's columns in blocks of block_w, dealt
+ * round-robin -- rank r of `world` renders the blocks r, r + world, ... over all rows.  A column strip per GPU leaves the
+ * GPUs whose strip shows sky idle (measured on configs[4]: the slowest of 8 strips takes 2.1x the mean, profiles/
+ * r03j_tile_balance.log); blocks of 16-64 columns even that out.  Same image, same reduce.  pt_set_tile(0,0,0,0) or
+ * pt_resize restore the whole image. */
+int pt_set_tile_interleaved(pt_ctx *ctx, uint32_t rank, uint32_t world, uint32_t block_w);
 
 #define PT_ACCUM_MEAN 0  /* running mean, mix(old,new,1/(frame+1)): raytrace.rgen:88-95 */
 #define PT_ACCUM_SUM 1   /* raw per-frame sums (exact, order-independent multi-GPU reduce) */

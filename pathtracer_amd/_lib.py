@@ -101,6 +101,7 @@ SYMBOLS = {
     "pt_write_ppm": (_i, [C.c_char_p, _vp, _u32, _u32]),
     "pt_image_extent": (_i, [_vp, _vp, _vp]),
     "pt_set_tile": (_i, [_vp, _u32, _u32, _u32, _u32]),
+    "pt_set_tile_interleaved": (_i, [_vp, _u32, _u32, _u32]),
     "pt_write_png": (_i, [C.c_char_p, _vp, _u32, _u32]),
     "pt_save_checkpoint": (_i, [_vp, C.c_char_p]),
     "pt_load_checkpoint": (_i, [_vp, C.c_char_p]),

@@ -312,6 +312,10 @@ class HipRaytracing:
         """Restrict dispatches to a sub-rectangle (image-tile split); w = h = 0: whole image."""
         self._check(self._L.pt_set_tile(self._ctx, x0, y0, w, h))
 
+    def setTileInterleaved(self, rank: int, world: int, block_w: int = 32):
+        """pt_set_tile_interleaved: blocks of `block_w` columns dealt round-robin, this context renders those of `rank`."""
+        self._check(self._L.pt_set_tile_interleaved(self._ctx, rank, world, block_w))
+
     def setAccumMode(self, mode):
         self._check(self._L.pt_set_accum_mode(self._ctx, mode))
 

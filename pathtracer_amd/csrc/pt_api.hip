@@ -90,7 +90,7 @@ struct pt_ctx
 
 	// frame state
 	uint32_t W = 0, H = 0;
-	PtTile tile = { 0, 0, 0, 0 };  // w == 0: the whole image
+	PtTile tile = { 0, 0, 0, 0, 0, 0 };  // w == 0: the whole image
 	int spp = 10, maxDepth = 20, maxFrames = 1000;
 	float tmin = 0.001f, tmax = 10000.0f;
 	uint32_t seed = 0;
@@ -1002,6 +1002,21 @@ extern "C" int pt_set_tile(pt_ctx *c, uint32_t x0, uint32_t y0, uint32_t w, uint
 	return PT_OK;
 }
 
+// Blocks of block_w columns dealt round-robin: rank r of `world` gets the blocks r, r + world, ... (all rows).
+extern "C" int pt_set_tile_interleaved(pt_ctx *c, uint32_t rank, uint32_t world, uint32_t block_w)
+{
+	if (!c) return fail(nullptr, PT_EINVAL, "null context");
+	if (!c->W) return fail(c, PT_EINVAL, "pt_set_tile_interleaved: no image (pt_resize)");
+	if (!world || rank >= world || !block_w) return fail(c, PT_EINVAL, "pt_set_tile_interleaved: rank %u of %u, blocks of %u columns", rank, world, block_w);
+	uint64_t columns = 0;
+	for (uint64_t x = (uint64_t)rank * block_w; x < c->W; x += (uint64_t)world * block_w)
+		columns += (c->W - x < block_w) ? c->W - x : block_w;
+	if (!columns)
+		return fail(c, PT_EINVAL, "pt_set_tile_interleaved: rank %u of %u gets no column of %u in blocks of %u", rank, world, c->W, block_w);
+	c->tile = PtTile{ rank * block_w, 0, (uint32_t)columns, c->H, block_w, world };
+	return PT_OK;
+}
+
 extern "C" int pt_set_camera(pt_ctx *c, const float view[16], const float proj[16])
 {
 	if (!c || !view || !proj) return fail(c, PT_EINVAL, "pt_set_camera: null argument");
@@ -1460,15 +1475,17 @@ namespace
 {
 struct CheckpointHeader
 {
-	char magic[8];  // "PTCKPT02" ("PTCKPT01": the same without the tile, read as the whole image)
+	char magic[8];  // "PTCKPT03" ("PTCKPT02": without tileBlock; "PTCKPT01": without the tile, read as the whole image)
 	uint32_t W, H;
 	int32_t frame, accumMode;
 	uint32_t firstFrame, frameStride, seed;
 	int32_t spp, maxDepth, maxFrames;
 	float tmin, tmax;
 	uint32_t tile[4];  // x0, y0, w, h of pt_set_tile; w = 0: the whole image
+	uint32_t tileBlock[2];  // "PTCKPT03": block width and stride of pt_set_tile_interleaved (0, 0: a rectangle)
 };
 constexpr size_t kCheckpointHeaderV1 = offsetof(CheckpointHeader, tile);
+constexpr size_t kCheckpointHeaderV2 = offsetof(CheckpointHeader, tileBlock);
 }  // namespace
 
 extern "C" int pt_save_checkpoint(pt_ctx *c, const char *path)
@@ -1481,7 +1498,7 @@ extern "C" int pt_save_checkpoint(pt_ctx *c, const char *path)
 		int rc = pt_read_image(c, px.data());
 		if (rc) return rc;
 		CheckpointHeader h;
-		memcpy(h.magic, "PTCKPT02", 8);
+		memcpy(h.magic, "PTCKPT03", 8);
 		h.W = c->W;
 		h.H = c->H;
 		h.frame = c->frame;
@@ -1498,6 +1515,8 @@ extern "C" int pt_save_checkpoint(pt_ctx *c, const char *path)
 		h.tile[1] = c->tile.y0;
 		h.tile[2] = c->tile.w;
 		h.tile[3] = c->tile.h;
+		h.tileBlock[0] = c->tile.bw;
+		h.tileBlock[1] = c->tile.stride;
 		FILE *f = fopen(path, "wb");
 		if (!f) return fail(c, PT_EIO, "pt_save_checkpoint: cannot open %s", path);
 		bool ok = fwrite(&h, sizeof(h), 1, f) == 1 && fwrite(px.data(), sizeof(float), px.size(), f) == px.size();
@@ -1522,7 +1541,9 @@ extern "C" int pt_load_checkpoint(pt_ctx *c, const char *path)
 	if (fread(&h, kCheckpointHeaderV1, 1, f) == 1)
 	{
 		if (memcmp(h.magic, "PTCKPT01", 8) == 0) headerBytes = kCheckpointHeaderV1;
-		else if (memcmp(h.magic, "PTCKPT02", 8) == 0 && fread(h.tile, sizeof(h.tile), 1, f) == 1) headerBytes = sizeof(h);
+		else if (memcmp(h.magic, "PTCKPT02", 8) == 0 && fread(h.tile, sizeof(h.tile), 1, f) == 1) headerBytes = kCheckpointHeaderV2;
+		else if (memcmp(h.magic, "PTCKPT03", 8) == 0 && fread(h.tile, sizeof(h.tile) + sizeof(h.tileBlock), 1, f) == 1)
+			headerBytes = sizeof(h);
 	}
 	if (!headerBytes || !h.W || !h.H || (uint64_t)h.W * h.H > 0x3FFFFFFFull)
 	{
@@ -1536,6 +1557,14 @@ extern "C" int pt_load_checkpoint(pt_ctx *c, const char *path)
 	else if (h.spp < 1 || h.maxDepth < 1 || h.maxDepth > PT_MAX_DEPTH) bad = "sampling parameters out of range";
 	else if (!(h.tmin >= 0.0f) || !(h.tmax > h.tmin)) bad = "ray interval out of range";
 	else if ((uint64_t)h.W * h.H * (uint64_t)h.spp > 0xFFFFFFF0ull) bad = "W*H*spp_per_frame exceeds 2^32 path ids";
+	else if (h.tileBlock[0] || h.tileBlock[1])
+	{
+		// an interleaved tile: its last column must lie inside the image (pt_tile_column of column w - 1)
+		const uint64_t bw = h.tileBlock[0], st = h.tileBlock[1], w = h.tile[2];
+		if (!bw || !st || !w || h.tile[1] != 0 || h.tile[3] != h.H || h.tile[0] % bw || h.tile[0] / bw >= st ||
+		    h.tile[0] + ((w - 1) / bw) * st * bw + (w - 1) % bw >= h.W)
+			bad = "interleaved tile does not fit the image";
+	}
 	else if (h.tile[2] || h.tile[3])
 	{
 		if (!h.tile[2] || !h.tile[3] || (uint64_t)h.tile[0] + h.tile[2] > h.W || (uint64_t)h.tile[1] + h.tile[3] > h.H)
@@ -1585,7 +1614,7 @@ extern "C" int pt_load_checkpoint(pt_ctx *c, const char *path)
 	c->firstFrame = h.firstFrame;
 	c->frameStride = h.frameStride;
 	c->accumMode = h.accumMode;
-	c->tile = PtTile{ h.tile[0], h.tile[1], h.tile[2], h.tile[3] };
+	c->tile = PtTile{ h.tile[0], h.tile[1], h.tile[2], h.tile[3], h.tileBlock[0], h.tileBlock[1] };
 	c->frame = h.frame;  // the next pt_render_frame renders frame + 1, as if the run had never stopped
 	return PT_OK;
 }

@@ -868,7 +868,7 @@ __global__ void __launch_bounds__(PT_WAVE) PT_PATHS_OCCUPANCY k_paths(PtPathsArg
 							const PtTile tile = PT_COLD(tile);
 							const uint32_t ty = p / tile.w;
 							genPy = tile.y0 + ty;
-							genPx = tile.x0 + (p - ty * tile.w);
+							genPx = pt_tile_column(tile, p - ty * tile.w);
 							genSeed = pt_tea(genPy * PT_COLD(W) + genPx, PT_COLD(seedWord) + f * PT_COLD(frameStride));  // rgen:28, val1 = seed + global frame
 							if (i)
 							{
@@ -1170,7 +1170,7 @@ __global__ void __launch_bounds__(256)
 	if (tt - lane >= WH) return;
 	const bool valid = tt < WH;
 	const uint32_t t = valid ? tt : 0u;
-	const uint32_t p = (tile.y0 + t / tile.w) * W + tile.x0 + t % tile.w;  // image pixel of tile pixel t
+	const uint32_t p = (tile.y0 + t / tile.w) * W + pt_tile_column(tile, t % tile.w);  // image pixel of tile pixel t
 	const size_t framePitch = (size_t)((WH + PT_WAVE - 1) / PT_WAVE) * spp * PT_WAVE;
 	size_t base = (size_t)(tt / PT_WAVE) * spp * PT_WAVE + lane;  // (tt / 64 is the same for the 64 lanes of a wave)
 	const float S = (float)spp;

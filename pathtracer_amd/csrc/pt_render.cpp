@@ -4,12 +4,13 @@
 //
 //   pt_render scene.obj [-w 800] [-h 600] [-spp 10] [-frames 100] [-depth 20] [-seed 0] [-tex map.png]
 //             (default: the first map_Kd of the OBJ's MTL file; `-tex none` renders untextured)
-//             [-o out.pfm|out.ppm|out.png] [-gpus G] [-devices 0,1,..] [-split streams|tiles] [-reduce rccl|host]
+//             [-o out.pfm|out.ppm|out.png] [-gpus G] [-devices 0,1,..] [-split streams|tiles|strips] [-reduce rccl|host]
 //
 // Defaults are the reference's constants (VulkanUtils.h:11-15, raytrace.rgen:22-23).
 // -gpus G: one host thread and one context per GPU (the rule of pathtracer_amd/multigpu.py): with
 // `streams` GPU r renders the global frames r, r+G, ... (frames rounded up to a multiple of G), with `tiles` every GPU renders
-// all frames of its own column strip; each accumulates raw sums (PT_ACCUM_SUM) against its own copy of the scene and BVH.
+// all frames of its own share of the image -- blocks of 32 columns dealt round-robin (pt_set_tile_interleaved; `strips`: one
+// column strip per GPU, which balances badly: profiles/r03j_tile_balance.log); each accumulates raw sums (PT_ACCUM_SUM) against its own copy of the scene and BVH.
 // The G sum images are then combined on GPU 0:
 //   -reduce rccl (default for G > 1)  ONE ncclReduce(sum, fp32, 4*W*H, root 0) over xGMI on the images where they lie
 //                (pt_image_device_ptr), a communicator per GPU from ncclCommInitAll -- the only exchange between the GPUs;
@@ -52,6 +53,7 @@ struct Job
 	int frames = 100;       // frames THIS context renders
 	uint32_t first = 0, stride = 1;
 	uint32_t tile[4] = { 0, 0, 0, 0 };  // w == 0: whole image
+	uint32_t ileave[3] = { 0, 0, 0 };   // rank, world, block width of pt_set_tile_interleaved (block width 0: not used)
 	int accum = PT_ACCUM_MEAN;
 	int device = 0;
 	// results
@@ -92,6 +94,7 @@ static int renderOn(Job &j)
 	CHECK(pt_set_frame_schedule(ctx, j.first, j.stride));
 	CHECK(pt_set_accum_mode(ctx, j.accum));
 	if (j.tile[2]) CHECK(pt_set_tile(ctx, j.tile[0], j.tile[1], j.tile[2], j.tile[3]));
+	if (j.ileave[2]) CHECK(pt_set_tile_interleaved(ctx, j.ileave[0], j.ileave[1], j.ileave[2]));
 	auto t0 = std::chrono::steady_clock::now();
 	CHECK(pt_render_frames(ctx, j.frames));
 	CHECK(pt_synchronize(ctx));
@@ -162,7 +165,7 @@ int main(int argc, char **argv)
 	pt_ctx *ctx = nullptr;
 	if (argc < 2)
 	{
-		fprintf(stderr, "usage: %s scene.obj [-w W] [-h H] [-spp S] [-frames F] [-depth D] [-seed X] [-tex map.png] [-o out.pfm|.ppm|.png] [-gpus G] [-devices a,b,..] [-split streams|tiles] [-reduce rccl|host]\n", argv[0]);
+		fprintf(stderr, "usage: %s scene.obj [-w W] [-h H] [-spp S] [-frames F] [-depth D] [-seed X] [-tex map.png] [-o out.pfm|.ppm|.png] [-gpus G] [-devices a,b,..] [-split streams|tiles|strips] [-reduce rccl|host]\n", argv[0]);
 		return EXIT_FAILURE;
 	}
 	std::string objPath = argv[1], out = "out.pfm", split = "streams", reduce = "";
@@ -199,8 +202,8 @@ int main(int argc, char **argv)
 			return EXIT_FAILURE;
 		}
 	}
-	if (gpus < 1 || (split != "streams" && split != "tiles") || (!devices.empty() && (int)devices.size() != gpus) ||
-	    (split == "tiles" && (uint32_t)gpus > base.W) || base.frames < 1 || (!reduce.empty() && reduce != "rccl" && reduce != "host"))
+	if (gpus < 1 || (split != "streams" && split != "tiles" && split != "strips") || (!devices.empty() && (int)devices.size() != gpus) ||
+	    (split != "streams" && (uint32_t)gpus > base.W) || base.frames < 1 || (!reduce.empty() && reduce != "rccl" && reduce != "host"))
 	{
 		fprintf(stderr, "bad -gpus / -devices / -split / -frames / -reduce\n");
 		return EXIT_FAILURE;
@@ -224,7 +227,8 @@ int main(int argc, char **argv)
 	}
 	if (base.texPath == "none") base.texPath.clear();
 	const uint32_t W = base.W, H = base.H;
-	const bool tiles = split == "tiles";
+	const bool tiles = split != "streams", strips = split == "strips";
+	const uint32_t kBlock = 32;  // columns per block of the interleaved schedule (multigpu.TILE_BLOCK_COLUMNS)
 	const int perGpu = tiles ? base.frames : (base.frames + gpus - 1) / gpus;
 	const int totalFrames = tiles ? base.frames : perGpu * gpus;
 	std::vector<Job> jobs((size_t)gpus, base);
@@ -236,7 +240,13 @@ int main(int argc, char **argv)
 		if (gpus > 1 || reduce == "rccl")
 		{
 			j.accum = PT_ACCUM_SUM;
-			if (tiles)
+			if (tiles && !strips && (uint64_t)gpus * kBlock <= W)
+			{
+				j.ileave[0] = (uint32_t)r;
+				j.ileave[1] = (uint32_t)gpus;
+				j.ileave[2] = kBlock;
+			}
+			else if (tiles)
 			{
 				const uint32_t b = W / (uint32_t)gpus, extra = W % (uint32_t)gpus, ur = (uint32_t)r;
 				j.tile[0] = ur * b + (ur < extra ? ur : extra);

@@ -7,12 +7,21 @@
 #define PT_STACK_CAPACITY (10 + PT_SPILL_STACK)  // smallest traversal stack of any kernel: LDS entries + spill
 #define PT_CHUNK 1024u      // queue records per chunk (work-claim and compaction granularity)
 
-// Sub-rectangle of the image a dispatch covers (pt_set_tile; default = the whole image).  Tile pixel t maps to
-// image pixel (x0 + t % w, y0 + t / w); seeds always use the full-image linear index y * W + x (rgen:28).
+// Part of the image a dispatch covers (default = the whole image); seeds always use the full-image linear index y * W + x
+// (rgen:28), so a pixel's value does not depend on the tiling.
+//   bw == 0 (pt_set_tile): the w x h rectangle at (x0, y0); tile pixel t = image pixel (x0 + t % w, y0 + t / w).
+//   bw != 0 (pt_set_tile_interleaved): blocks of bw columns dealt round-robin -- this tile holds every `stride`-th block
+//   beginning with the one at column x0; w counts the tile's columns (the image's last block may be cut short), and tile
+//   column c = image column x0 + (c / bw) * stride * bw + c % bw.
 struct PtTile
 {
 	uint32_t x0, y0, w, h;
+	uint32_t bw, stride;
 };
+__host__ __device__ inline uint32_t pt_tile_column(const PtTile &t, uint32_t c)
+{
+	return t.bw ? t.x0 + (c / t.bw) * t.stride * t.bw + c % t.bw : t.x0 + c;
+}
 
 // Per-frame device counters, zeroed by k_frame_begin.  count[d] = rays queued for bounce d.
 struct PtFrameCounters

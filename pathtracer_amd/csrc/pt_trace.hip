@@ -153,7 +153,7 @@ __global__ void __launch_bounds__(kBlock)
 	uint32_t p = blockIdx.x * kBlock + threadIdx.x;
 	const uint32_t WH = tile.w * tile.h;  // paths are numbered inside the tile
 	if (p >= WH) return;
-	uint32_t px = tile.x0 + p % tile.w, py = tile.y0 + p / tile.w;
+	uint32_t px = pt_tile_column(tile, p % tile.w), py = tile.y0 + p / tile.w;
 	uint32_t seed = pt_tea(py * W + px, seedWord);  // raytrace.rgen:28 with val1 = seed + global frame
 	for (uint32_t i = 0; i < spp; ++i)
 	{
@@ -319,7 +319,7 @@ __global__ void __launch_bounds__(kBlock)
 	uint32_t t = blockIdx.x * kBlock + threadIdx.x;
 	const uint32_t WH = tile.w * tile.h;
 	if (t >= WH) return;
-	const uint32_t p = (tile.y0 + t / tile.w) * W + tile.x0 + t % tile.w;  // image pixel of tile pixel t
+	const uint32_t p = (tile.y0 + t / tile.w) * W + pt_tile_column(tile, t % tile.w);  // image pixel of tile pixel t
 	float ax = 0.0f, ay = 0.0f, az = 0.0f;
 	for (uint32_t i = 0; i < spp; ++i)
 	{

@@ -223,9 +223,9 @@ def test_tiled_checkpoint_resume_and_header_validation(pa, cornell, tmp_path):
     assert np.array_equal(bits(b.readImage()), bits(want))  # columns outside the strip are still zero
     # corrupt headers: frame index, stride, spp, tile -- each refused, the context keeps rendering as before
     blob = bytearray(open(ck, "rb").read())
-    assert blob[:8] == b"PTCKPT02"
+    assert blob[:8] == b"PTCKPT03"  # (round 3: + block width and stride of an interleaved tile, 8 bytes behind the tile)
     fields = {"frame": (16, "<i", -7), "frame_big": (16, "<i", 0x7FFFFFFF), "stride": (28, "<I", 0), "spp": (36, "<i", 0),
-              "tile_w": (64, "<I", 1000)}
+              "tile_w": (64, "<I", 1000), "tile_block_without_stride": (72, "<I", 8)}
     for name, (off, fmt, val) in fields.items():
         bad = bytearray(blob)
         struct.pack_into(fmt, bad, off, val)
@@ -239,10 +239,16 @@ def test_tiled_checkpoint_resume_and_header_validation(pa, cornell, tmp_path):
     with pytest.raises(pa.PathTracerError):
         b.loadCheckpoint(str(tmp_path / "short.ckpt"))
     # a version-1 file (no tile) still loads, as the whole image
-    v1 = b"PTCKPT01" + bytes(blob[8:56]) + bytes(blob[72:])
+    v1 = b"PTCKPT01" + bytes(blob[8:56]) + bytes(blob[80:])
     open(tmp_path / "v1.ckpt", "wb").write(v1)
     b.loadCheckpoint(str(tmp_path / "v1.ckpt"))
     assert b.frame == 0
+    # ... and a version-2 file (a rectangular tile, no block fields) as that tile: the resumed run equals the uninterrupted one
+    v2 = b"PTCKPT02" + bytes(blob[8:72]) + bytes(blob[80:])
+    open(tmp_path / "v2.ckpt", "wb").write(v2)
+    b.loadCheckpoint(str(tmp_path / "v2.ckpt"))
+    b.raytrace(3)
+    assert np.array_equal(bits(b.readImage()), bits(want))
     b.cleanup()
 
 

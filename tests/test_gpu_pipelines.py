@@ -149,6 +149,53 @@ def test_tiles_reproduce_the_full_image(rt, pa, cornell, ocornell, pipeline):
     assert np.array_equal(bits(rt.readImage()), bits(want))
 
 
+@pytest.mark.parametrize("pipeline", sorted(PIPELINES))
+def test_interleaved_tiles_reproduce_the_full_image(rt, pa, cornell, ocornell, pipeline, tmp_path):
+    """pt_set_tile_interleaved: blocks of 7 columns dealt round-robin to 3 ranks (150 columns: the last block is cut short and
+    the ranks get 52 / 49 / 49 columns): every rank's image equals the oracle on its columns and is zero elsewhere, the three
+    sum to the full image bit for bit, rays add up; a checkpoint taken on an interleaved tile resumes on it."""
+    from pathtracer_amd import multigpu
+    from pathtracer_amd.api import PT_ACCUM_SUM
+    W, H, G, B = 150, 67, 3, 7
+    view, proj = pa.reference_camera(W, H)
+    rt.setPipeline(PIPELINES[pipeline])
+    rt.buildBlas(cornell)
+    rt.resize(W, H)
+    rt.setCamera(view, proj)
+    rt.setParams(spp_per_frame=3, max_depth=6, seed=2)
+    rt.setAccumMode(PT_ACCUM_SUM)
+    want, rays = ocornell.render(view, proj, W, H, frames=3, spp_per_frame=3, max_depth=6, seed=2, accum_sum=True)
+    total = np.zeros_like(want)
+    nrays = 0
+    seen = []
+    for r in range(G):
+        cols = multigpu.interleaved_columns(r, G, W, B)
+        seen += cols
+        rt.resize(W, H)  # zeroes the image, clears the tile
+        rt.setTileInterleaved(r, G, B)
+        rt.resetStats()
+        rt.raytrace(2)
+        if r == 1:
+            ck = str(tmp_path / "tile.ckpt")
+            rt.saveCheckpoint(ck)
+            rt.resize(W, H)
+            rt.loadCheckpoint(ck)
+        rt.raytrace(1)
+        img = rt.readImage()
+        inside = np.zeros((H, W), dtype=bool)
+        inside[:, cols] = True
+        assert np.array_equal(bits(img[inside]), bits(want[inside]))
+        assert np.all(img[~inside] == 0.0)
+        assert rt.stats().paths_last_frame == len(cols) * H * 3
+        total += img
+        nrays += rt.stats().rays_total
+    assert sorted(seen) == list(range(W))
+    assert np.array_equal(bits(total[..., :3]), bits(want[..., :3])) and nrays == rays
+    for bad in ((3, 3, 7), (0, 0, 7), (0, 3, 0), (2, 3, 75)):  # rank outside the world; no world; no block; a rank without a column
+        with pytest.raises(pa.PathTracerError):
+            rt.setTileInterleaved(*bad)
+
+
 def test_many_frames_per_launch_equal_frame_by_frame(rt, pa, cornell, ocornell):
     """pt_render_frames(n) puts up to PT_FRAMES_PER_LAUNCH (8) frames into one launch of the persistent kernel:
     19 frames in one call (launches of 8 + 8 + 3) == 19 single-frame calls == the oracle, bit for bit; the

@@ -94,6 +94,11 @@ def test_pt_render_one_and_two_contexts(pa, tmp_path):
     assert np.array_equal(bits(read_pfm(outp)), bits(want3[..., :3]))
     run(common + ["-gpus", "3", "-devices", "0,0,0", "-split", "tiles", "-o", out3])
     assert os.path.getsize(out3) > 100
+    # two contexts: 2 x 32 columns fit the 72 of the image, so `tiles` deals blocks of 32 columns round-robin
+    # (pt_set_tile_interleaved: context 0 renders columns 0-31 and 64-71, context 1 columns 32-63); `strips` = one strip each
+    for split in ("tiles", "strips"):
+        run(common + ["-gpus", "2", "-devices", "0,0", "-split", split, "-o", outp])
+        assert np.array_equal(bits(read_pfm(outp)), bits(want3[..., :3]))
 
 
 def test_pt_render_rccl_reduce_one_rank_and_device_side_srgb(pa, tmp_path):

@@ -95,6 +95,17 @@ def _tile_worker(rank, world, port, frames, out_path):
     dist.destroy_process_group()
 
 
+def test_interleaved_columns_partition_the_image():
+    from pathtracer_amd import multigpu
+    for world, W, B in ((1, 7, 32), (2, 33, 4), (8, 1920, 32), (8, 1921, 32), (3, 150, 7), (5, 40, 16)):
+        cols = sorted(x for r in range(world) for x in multigpu.interleaved_columns(r, world, W, B))
+        assert cols == list(range(W))
+        counts = [len(multigpu.interleaved_columns(r, world, W, B)) for r in range(world)]
+        assert max(counts) - min(counts) <= B
+    with pytest.raises(ValueError):
+        multigpu.interleaved_columns(2, 2, 10)
+
+
 def test_tile_schedule_partitions_columns():
     from pathtracer_amd import multigpu
     for world, W in ((1, 7), (2, 33), (8, 1920), (8, 1921), (3, 3)):
