@@ -1101,7 +1101,9 @@ int ensurePersistent(pt_ctx *c, size_t records, bool flatScene, bool *outOfMemor
 {
 	*outOfMemory = false;
 	const size_t ringRecords = (size_t)c->cfg.bounceWaves * PT_PATHS_RING;
-	size_t stateRecords = flatScene ? ringRecords : (records < ringRecords ? ringRecords : records);
+	// (the flat kernel keeps no state record per path only when it is BUILT to carry the state with the ray)
+	const bool ringOnly = flatScene && PT_FLAT_CARRY_STATE != 0;
+	size_t stateRecords = ringOnly ? ringRecords : (records < ringRecords ? ringRecords : records);
 	if (records > c->pCap || stateRecords > c->pStateCap)
 	{
 		PT_HIP(c, hipStreamSynchronize(c->stream));
@@ -1110,8 +1112,10 @@ int ensurePersistent(pt_ctx *c, size_t records, bool flatScene, bool *outOfMemor
 		hipFree(c->pLit);
 		c->pState = c->pRad = nullptr;
 		c->pLit = nullptr;
-		if (records < c->pCap) records = c->pCap;  // never shrink what a caller has grown
-		if (stateRecords < c->pStateCap) stateRecords = c->pStateCap;
+		// Both buffers are sized for THIS request (the caller planned it against the memory budget): a request that fits what
+		// is there never gets here, so smaller calls between larger ones do not reallocate -- and a context that goes from a
+		// flat scene (radiance for twice the frames, no state table) to one with a tree does not keep the larger radiance
+		// buffer beside a full state table.
 		c->pCap = c->pStateCap = 0;
 		hipError_t e = hipMalloc(&c->pState, stateRecords * sizeof(float4));
 		if (e == hipSuccess) e = hipMalloc(&c->pRad, records * sizeof(float4));
@@ -1150,23 +1154,28 @@ int renderPersistent(pt_ctx *c, int n, bool noAlloc = false)
 	// frames per launch: path ids q = item * 64 + lane stay below 2^32, state + radiance stay below the memory budget
 	// the flat-scene kernel keeps no state record per path (ptLaunchPaths: the same test), so the budget buys it twice the frames
 	const bool flatScene = c->dEntry && c->entryFlat && !(c->tlasDepth ? c->nInst : 0) && c->nIdx / 3 < 255u;
-	const size_t pathBytes = flatScene && !noAlloc ? sizeof(float4) : 2 * sizeof(float4);  // (the scratch array's slices are fixed)
-	size_t perLaunch = (size_t)c->framesPerLaunch * (flatScene && !c->framesPerLaunchSet ? 2 : 1);
+	const bool ringOnly = flatScene && PT_FLAT_CARRY_STATE != 0;
+	const size_t pathBytes = ringOnly && !noAlloc ? sizeof(float4) : 2 * sizeof(float4);  // (the scratch array's slices are fixed)
+	size_t perLaunch = (size_t)c->framesPerLaunch * (ringOnly && !c->framesPerLaunchSet ? 2 : 1);
 	if (perLaunch * nPadded > 0xFFFFFF00ull) perLaunch = 0xFFFFFF00ull / nPadded;
 	size_t budget = c->persistentBytes;
 	if (noAlloc) budget = 2 * kNaRecBytes;
-	else
+	if (perLaunch * nPadded * pathBytes > budget) perLaunch = budget / (nPadded * pathBytes);
+	if (perLaunch < 1) perLaunch = 1;
+	const size_t firstRequest = nPadded * (n > 1 ? perLaunch : (size_t)1);  // (what the loop below asks ensurePersistent for)
+	if (!noAlloc && (firstRequest > c->pCap || (!ringOnly && firstRequest > c->pStateCap)))
 	{
-		// never plan for more than half of what the device has left (plus what these buffers already hold)
+		// the buffers will have to grow (only then is the driver asked): never plan for more than half of what the device has
+		// left, plus what these buffers already hold -- a frame-by-frame caller whose buffers are in place pays no query
 		size_t freeB = 0, totalB = 0;
 		if (hipMemGetInfo(&freeB, &totalB) == hipSuccess)
 		{
 			const size_t room = (freeB + (c->pCap + c->pStateCap) * sizeof(float4)) / 2;
 			if (room < budget) budget = room;
+			if (perLaunch * nPadded * pathBytes > budget) perLaunch = budget / (nPadded * pathBytes);
+			if (perLaunch < 1) perLaunch = 1;
 		}
 	}
-	if (perLaunch * nPadded * pathBytes > budget) perLaunch = budget / (nPadded * pathBytes);
-	if (perLaunch < 1) perLaunch = 1;
 	if (nPadded > 0xFFFFFF00ull) return fail(c, PT_EINVAL, "pt_render_frame: %zu paths per frame exceed 2^32", nPadded);
 	hipStream_t s = c->stream;
 	int rc = PT_OK;

@@ -128,11 +128,7 @@ constexpr bool kFlatCull = PT_FLAT_CULL != 0;
 #define PT_RING_LIFO 1
 #endif
 constexpr bool kRingLifoOn = PT_RING_LIFO != 0;
-// flat scenes: throughput and RNG state travel with the ray (third ring record, four more staging and done rows) instead of
-// living in a per-path table in memory that the shading pass has to gather from
-#ifndef PT_FLAT_CARRY_STATE
-#define PT_FLAT_CARRY_STATE 1
-#endif
+// (PT_FLAT_CARRY_STATE: pt_trace.h -- the host sizes the state buffer by it)
 #ifndef PT_RING_PREFETCH
 #define PT_RING_PREFETCH 1
 #endif

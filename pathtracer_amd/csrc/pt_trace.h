@@ -6,6 +6,13 @@
 #define PT_SPILL_STACK 72   // traversal stack entries per lane beyond the LDS-resident ones
 #define PT_STACK_CAPACITY (10 + PT_SPILL_STACK)  // smallest traversal stack of any kernel: LDS entries + spill
 #define PT_CHUNK 1024u      // queue records per chunk (work-claim and compaction granularity)
+// k_paths on flat scenes (every child of the entry node a leaf): throughput and RNG state travel with the ray (third ring
+// record, four more staging and done rows) instead of living in a per-path table that the shading pass has to gather from.
+// Kernel AND host read this switch: with it the host allocates only the ring part of the state buffer for such a scene
+// (pt_api.hip, ensurePersistent); a kernel built without it writes one state record per path.
+#ifndef PT_FLAT_CARRY_STATE
+#define PT_FLAT_CARRY_STATE 1
+#endif
 
 // Part of the image a dispatch covers (default = the whole image); seeds always use the full-image linear index y * W + x
 // (rgen:28), so a pixel's value does not depend on the tiling.
