@@ -1338,6 +1338,37 @@ __global__ void __launch_bounds__(kBlock) k_quad_flag(const PtNode4 *nodes, uint
 	flags[i] = f;
 }
 
+// The same test over a SAMPLE of the node array (the last `nSample` nodes: breadth-first numbering puts the leaves there),
+// counted: count[0] += fan pairs, count[1] += triangles in leaves.  A scene of millions of nodes whose leaves do not pair up
+// (a triangle soup) is told apart here for the price of the sample, not of a pass over every node and triangle.
+__global__ void __launch_bounds__(kBlock) k_quad_sample(const PtNode4 *nodes, uint32_t firstNode, uint32_t nSample, const PtTri48 *plane2,
+                                                        unsigned long long *count)
+{
+	const uint32_t i = blockIdx.x * kBlock + threadIdx.x;
+	uint32_t pair = 0, tris = 0;
+	if (i < 4u * nSample)
+	{
+		const uint32_t ref = nodes[firstNode + (i >> 2)].child[i & 3u];
+		if ((ref & PT_LEAF_FLAG) && ref < PT_INSTANCE_END)
+		{
+			tris = ((ref >> 28) & 7u) + 1u;
+			if (quadCandidate(ref))
+			{
+				const uint32_t first = ref & 0x0FFFFFFFu;
+				pair = quadPattern(plane2[first], plane2[first + 1]) != 0 ? 1u : 0u;
+			}
+		}
+	}
+	const unsigned long long pm = __ballot(pair != 0);
+#pragma unroll
+	for (int o = 32; o > 0; o >>= 1) tris += __shfl_xor(tris, o);
+	if ((threadIdx.x & 63) == 0)
+	{
+		if (pm) atomicAdd(&count[0], (unsigned long long)__popcll(pm));
+		if (tris) atomicAdd(&count[1], (unsigned long long)tris);
+	}
+}
+
 // index = exclusive scan of the flags.  Writes the quad records (all three planes, from the triangle records of the same
 // plane) and patches the child reference in the copy of the node array.
 __global__ void __launch_bounds__(kBlock)
@@ -1383,7 +1414,26 @@ hipError_t ptBuildQuadLeaves(const PtNode4 *nodes, uint32_t nNodes, const PtTri4
 	const size_t nSlots = 4 * (size_t)nNodes;
 	uint32_t *flags = nullptr;
 	const size_t words = ((nSlots + 63) & ~(size_t)63) + scanScratchLen(nSlots) + 64;
-	hipError_t e = hipMalloc(&flags, 4 * words);
+	hipError_t e = hipSuccess;
+	constexpr uint32_t kSample = 1u << 16;
+	if (nNodes > 8u * kSample)
+	{
+		// big trees: look at the last 65 536 nodes first; when not even half of the share asked for pairs up there, the scene
+		// is not made of quads (100 M-triangle soup: 2 ms of flagging, scanning and reading 7 GB saved per build)
+		unsigned long long *count = nullptr, h[2] = { 0, 0 };
+		e = hipMalloc(&count, sizeof(h));
+		if (e == hipSuccess) e = hipMemsetAsync(count, 0, sizeof(h), stream);
+		if (e == hipSuccess)
+		{
+			k_quad_sample<<<divUp(4u * kSample, kBlock), kBlock, 0, stream>>>(nodes, nNodes - kSample, kSample, tris + 2 * (size_t)nTris, count);
+			e = hipMemcpyAsync(h, count, sizeof(h), hipMemcpyDeviceToHost, stream);
+		}
+		if (e == hipSuccess) e = hipStreamSynchronize(stream);
+		hipFree(count);
+		if (e != hipSuccess) return e;
+		if (2.0 * (double)h[0] < 0.5 * (double)minShare * (double)h[1]) return hipSuccess;
+	}
+	e = hipMalloc(&flags, 4 * words);
 	if (e != hipSuccess) return e;
 	uint32_t *scratch = flags + ((nSlots + 63) & ~(size_t)63), *total = flags + words - 64;
 	k_quad_flag<<<divUp((uint32_t)nSlots, kBlock), kBlock, 0, stream>>>(nodes, nNodes, tris + 2 * (size_t)nTris, flags);

@@ -253,3 +253,36 @@ def test_quad_leaves_bit_exact(rt, pa, O, nx, nz, reverse_every, drop_every):
     print("quad leaves (lbvh, ploc):", quads, "of", sc.n_tris // 2, "faces")
     if drop_every != 2:
         assert max(quads) > 0, quads  # at least one builder keeps the faces together
+
+
+def test_quad_leaves_of_a_big_scene_pass_the_sampled_check(rt, pa):
+    """Trees above 2^19 nodes are first checked on a sample (their last 65 536 nodes) before every slot is flagged: a scene of
+    2.25 M separate quad tiles (750 K nodes) still gets its quad leaves -- as many as the same tiles in one piece less would
+    predict -- and a soup of as many random triangles gets none."""
+    n = 1500
+    rng = np.random.default_rng(3)
+    gx, gz = np.meshgrid(np.arange(n, dtype=np.float32), np.arange(n, dtype=np.float32), indexing="xy")
+    cx = (gx.reshape(-1) + 0.5 + rng.uniform(-0.1, 0.1, n * n).astype(np.float32)) * np.float32(2.0 / n) - np.float32(1.0)
+    cz = (gz.reshape(-1) + 0.5 + rng.uniform(-0.1, 0.1, n * n).astype(np.float32)) * np.float32(2.0 / n) - np.float32(1.0)
+    cy = rng.uniform(0.0, 0.3, n * n).astype(np.float32)
+    h = np.float32(0.7 / n)
+    F = n * n
+    verts = np.zeros((4 * F, 11), dtype=np.float32)
+    for k, (dx, dz) in enumerate([(-h, -h), (h, -h), (h, h), (-h, h)]):
+        verts[k::4, 0] = cx + dx
+        verts[k::4, 1] = cy + rng.uniform(-0.3, 0.3, F).astype(np.float32) * h
+        verts[k::4, 2] = cz + dz
+    verts[:, 4] = 1.0
+    verts[:, 6:9] = 1.0
+    base = (4 * np.arange(F, dtype=np.uint32))[:, None]
+    idx = (base + np.array([0, 1, 2, 0, 2, 3], dtype=np.uint32)[None, :]).reshape(-1)
+    mats = np.array([[0.7, 0.6, 0.5, 0, 0, 0]], dtype=np.float32)
+    sc = pa.Scene(verts, idx, mats, np.zeros(2 * F, np.uint32))
+    rt.buildBlas(sc, BUILDERS["ploc"])
+    st = rt.stats()
+    assert st.bvh_nodes > (1 << 19)
+    assert st.quad_leaves >= 0.9 * F, (st.quad_leaves, F)
+    soup = pa.scenes.random_triangles(2 * F, extent=300.0, edge=1.0)
+    rt.buildBlas(soup, BUILDERS["lbvh"])
+    st = rt.stats()
+    assert st.bvh_nodes > (1 << 19) and st.quad_leaves == 0
