@@ -217,11 +217,12 @@ def build_scene(a, pa):
         # neither mesh comes with a .mtl or an emitter in the reference (all grey, black image): one light quad is added
         sc = pa.scenes.with_light_quad(reference_mesh(pa, "viking_room"),
                                        [[-2.0, -2.0, 2.0], [2.0, -2.0, 2.0], [2.0, 2.0, 2.0], [-2.0, 2.0, 2.0]], (0, 0, -1))
-        a.texture = np.random.default_rng(3).integers(0, 256, (1024, 1024, 4), dtype=np.uint8)  # the size of textures/viking_room.png
+        # the texels of the reference's textures/viking_room.png (decoded in the build container: tests/golden/make_viking_texture.py)
+        a.texture = np.load(os.path.join(ROOT, "tests", "golden", "viking_room_texels.npz"))["rgba8"]
         view = pa.look_at((1.3, 1.3, 1.2), (0.05, 0.0, 0.3), (0.0, 0.0, 1.0))
         proj = pa.perspective(math.radians(45.0), W / H, 0.1, 10.0)
         proj[5] *= -1
-        return sc, view, proj, 1e4, f"viking_room.obj ({sc.n_tris} triangles) with a 1024x1024 diffuse map"
+        return sc, view, proj, 1e4, f"viking_room.obj ({sc.n_tris} triangles) with its 1024x1024 diffuse map (textures/viking_room.png)"
     if a.scene == "teapot":
         sc = pa.scenes.with_light_quad(reference_mesh(pa, "teapot"),
                                        [[-3.0, 5.0, -3.0], [3.0, 5.0, -3.0], [3.0, 5.0, 3.0], [-3.0, 5.0, 3.0]], (0, -1, 0))

@@ -413,9 +413,15 @@ __global__ void __launch_bounds__(PT_WAVE) PT_PATHS_OCCUPANCY k_paths(PtPathsArg
 				float u, v;
 				if (pt_all_in_division_range(det, V, W))  // same quotients, the reciprocal refined once (pt_device_common.h)
 				{
+#ifdef PT_PROBE_RCPDET
+					const float rcpDet = PtSharedDivisor(det).quotient(1.0f);  // (speed probe only: changes results)
+					u = V * rcpDet;
+					v = W * rcpDet;
+#else
 					const PtSharedDivisor by(det);
 					u = by.quotient(V);
 					v = by.quotient(W);
+#endif
 				}
 				else
 				{

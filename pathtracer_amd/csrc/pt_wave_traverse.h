@@ -38,6 +38,15 @@ __device__ __forceinline__ PtLaneRay pt_prepare_ray(float3x o, float3x d)
 	// 2^+-40: then v_div_scale scales nothing, v_div_fmas is a plain fma and v_div_fixup returns its input) the same
 	// instructions are issued with that part shared -- 18 instead of 33, bit-identical quotients; otherwise, and always where
 	// lanes call this one by one (kShareReciprocal == false), the plain divisions.
+#ifdef PT_PROBE_RCPDET
+	// speed probe only (changes results): Sz = 1 / d[kz] once, Sx = d[kx] * Sz, Sy = d[ky] * Sz
+	if (kShareReciprocal && pt_all_in_division_range(dkz, dkx, dky))
+	{
+		r.Sz = PtSharedDivisor(dkz).quotient(1.0f);
+		r.Sx = dkx * r.Sz;
+		r.Sy = dky * r.Sz;
+	}
+#else
 	if (kShareReciprocal && pt_all_in_division_range(dkz, dkx, dky))
 	{
 		const PtSharedDivisor by(dkz);
@@ -45,6 +54,7 @@ __device__ __forceinline__ PtLaneRay pt_prepare_ray(float3x o, float3x d)
 		r.Sy = by.quotient(dky);
 		r.Sz = by.quotient(1.0f);
 	}
+#endif
 	else
 	{
 		r.Sx = dkx / dkz;

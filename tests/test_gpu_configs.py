@@ -9,6 +9,8 @@ renders add ONE emissive quad (scenes.with_light_quad) that the reference does n
 CPU oracle on random pixel samples, bit for bit; full-size runs are checked through size-independent properties."""
 import math
 
+import os
+
 import numpy as np
 import pytest
 
@@ -56,11 +58,14 @@ def test_config2_viking_room_reference_behaviour_all_grey(rt, pa, O, ref_mesh):
 
 
 def test_config2_viking_room_4k_textured_pixel_sample(rt, pa, O, ref_mesh):
-    """BASELINE configs[2]: viking_room.obj, 3840x2160, a 1024^2 diffuse map (the size of textures/viking_room.png; random
-    texels), depth 8, the frame rank 3 of 8 renders first (global frame 3).  3 000 random pixels against the oracle."""
+    """BASELINE configs[2]: viking_room.obj, 3840x2160, with the reference's own diffuse map -- the texels of
+    textures/viking_room.png (tests/golden/viking_room_texels.npz, decoded in the build container by
+    tests/golden/make_viking_texture.py) -- depth 8, the frame rank 3 of 8 renders first (global frame 3).  3 000 random
+    pixels against the oracle."""
     W, H, S = 3840, 2160, 4
     sc = viking_room(pa, ref_mesh)
-    tex = np.random.default_rng(3).integers(0, 256, (1024, 1024, 4), dtype=np.uint8)
+    tex = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "viking_room_texels.npz"))["rgba8"]
+    assert tex.shape == (1024, 1024, 4) and tex.dtype == np.uint8 and len(np.unique(tex[..., 0])) > 100
     view, proj = viking_camera(pa, W, H)
     rt.buildBlas(sc)
     rt.setTexture(tex)

@@ -116,6 +116,9 @@ def test_reference_texture_decodes_like_zlib(pa):
         want = np.cumsum(raw[rows, 1:].reshape(len(rows), 1024, 3).astype(np.int64), axis=1) & 255
         assert np.array_equal(got[rows, :, :3], want)
     assert len(np.unique(raw[:, 0])) >= 2
+    # the committed fixture the GPU box renders configs[2] with (decoded by Pillow: tests/golden/make_viking_texture.py)
+    gold = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "viking_room_texels.npz"))["rgba8"]
+    assert np.array_equal(got, gold)
 
 
 def test_srgb_table_matches_oracle(pa, O):
