@@ -18,6 +18,8 @@ PT_ACCEL_BRUTE_FORCE = 1
 PT_ACCEL_BVH4_PLOC = 2
 PT_ACCEL_NO_COMPACTION = 0x1000
 PT_ACCEL_NO_ENTRY_NODE = 0x2000
+PT_ACCEL_TRI_PLANES_1 = 0x4000
+PT_ACCEL_TRI_PLANES_3 = 0x8000
 PT_ACCEL_LEAF_SIZE_1 = 1 << 8  # PT_ACCEL_LEAF_SIZE(1)
 
 

@@ -15,7 +15,7 @@ from dataclasses import dataclass
 import numpy as np
 
 from . import _lib
-from ._lib import (PT_ACCEL_BRUTE_FORCE, PT_ACCEL_BVH4, PT_ACCEL_BVH4_PLOC, PT_ACCEL_LEAF_SIZE, PT_ACCEL_LEAF_SIZE_1, PT_ACCEL_NO_COMPACTION, PT_ACCEL_NO_ENTRY_NODE, PT_ACCUM_MEAN, PT_ACCUM_SUM, PT_NO_HIT, PT_PROFILE_KERNELS,
+from ._lib import (PT_ACCEL_BRUTE_FORCE, PT_ACCEL_BVH4, PT_ACCEL_BVH4_PLOC, PT_ACCEL_LEAF_SIZE, PT_ACCEL_LEAF_SIZE_1, PT_ACCEL_NO_COMPACTION, PT_ACCEL_NO_ENTRY_NODE, PT_ACCEL_TRI_PLANES_1, PT_ACCEL_TRI_PLANES_3, PT_ACCUM_MEAN, PT_ACCUM_SUM, PT_NO_HIT, PT_PROFILE_KERNELS,
                    PT_PROFILE_TRAVERSAL, PT_PIPELINE_FUSED, PT_PIPELINE_SPLIT, PT_PIPELINE_PERSISTENT, PtStats)
 
 HIT_DTYPE = np.dtype([("t", np.float32), ("u", np.float32), ("v", np.float32), ("prim", np.uint32)])

@@ -233,6 +233,7 @@ PtSceneDev sceneDev(const pt_ctx *c)
 	s.shade = c->dShade;
 	s.nodes = c->accel.nodes;
 	s.tris = c->accel.tris;  // plane 0; plane r at tris + r * nTris
+	s.triPlanes = (uint32_t)c->accel.triPlanes;
 	s.nTris = c->nIdx / 3;
 	s.nNodes = c->accel.nNodes;
 	s.texture = c->dTexture;
@@ -724,7 +725,8 @@ extern "C" int pt_build_accel(pt_ctx *c, int flags) try
 	if (!c->haveScene) return fail(c, PT_EINVAL, "pt_build_accel: no scene uploaded");
 	const int mode = flags & 0xFF, leafMax = (flags >> 8) & 0xF;
 	const bool compact = !(flags & PT_ACCEL_NO_COMPACTION);
-	if ((mode != PT_ACCEL_BVH4 && mode != PT_ACCEL_BRUTE_FORCE && mode != PT_ACCEL_BVH4_PLOC) || (flags & ~0x3FFF) || leafMax > 8)
+	if ((mode != PT_ACCEL_BVH4 && mode != PT_ACCEL_BRUTE_FORCE && mode != PT_ACCEL_BVH4_PLOC) || (flags & ~0xFFFF) || leafMax > 8 ||
+	    ((flags & PT_ACCEL_TRI_PLANES_1) && (flags & PT_ACCEL_TRI_PLANES_3)))
 		return fail(c, PT_EINVAL, "pt_build_accel: bad flags 0x%x", flags);
 	PT_HIP(c, hipSetDevice(c->device));
 	PT_HIP(c, hipStreamSynchronize(c->stream));
@@ -758,6 +760,14 @@ extern "C" int pt_build_accel(pt_ctx *c, int flags) try
 	// them); brute-force mode just does not traverse the hierarchy.
 	PtBuildInput in = { c->dVerts, c->dIndices, c->nIdx / 3, leafMax,
 	                    mode == PT_ACCEL_BVH4_PLOC ? PT_BUILDER_PLOC : PT_BUILDER_LBVH };
+	// Leaf triangle records once per dominant ray axis (the traversal then spends nothing per triangle on the permutation) --
+	// or, for one big Model, the identity plane only: at PT_ONE_PLANE_TRIS triangles and above the traversal waits for memory
+	// (DESIGN.md 5.3c), the selects are free and a third of the footprint caches better (measured, profiles/r03p/q_ab_planes*:
+	// soup of 1 M / 4 M / 20 M triangles +1.0 / +4.1 / +1.3 % with one plane, viking_room and the teapot grid -1 %), while the
+	// two extra planes are 96 B per triangle to write and to keep (100 M triangles: 9.6 GB, 2.3 ms of the build).  Scenes of
+	// several Models keep three planes.
+	in.triPlanes = 3;
+	if (nModels == 1 && !(flags & PT_ACCEL_TRI_PLANES_3) && ((flags & PT_ACCEL_TRI_PLANES_1) || c->nIdx / 3 >= PT_ONE_PLANE_TRIS)) in.triPlanes = 1;
 	hipEvent_t a = getEvent(c), b = getEvent(c);
 	const bool timed = a && b;  // without events the build is simply not timed
 	if (timed) hipEventRecord(a, c->stream);
@@ -839,7 +849,7 @@ extern "C" int pt_build_accel(pt_ctx *c, int flags) try
 		// cmdCompactBlas (VulkanRaytracing.cpp:300-380): the builder sizes the node array for the worst case (one wide
 		// node per primitive); copy the nodes actually produced into an exact-size allocation and release the rest
 		const uint64_t nPrims = c->nIdx / 3;
-		const uint64_t fixed = nPrims * (3 * sizeof(PtTri48) + 8);  // leaf triangles (three planes) + codes + order
+		const uint64_t fixed = nPrims * ((uint64_t)c->accel.triPlanes * sizeof(PtTri48) + 8);  // leaf triangles (three planes, or one) + codes + order
 		c->accelBytesUncompacted = fixed + nPrims * sizeof(PtNode4);
 		c->accelBytes = c->accelBytesUncompacted;
 		if (nModels > 1) c->accelBytes = fixed + (uint64_t)c->accel.nNodes * sizeof(PtNode4);  // assembled at its exact size
@@ -862,7 +872,8 @@ extern "C" int pt_build_accel(pt_ctx *c, int flags) try
 	if (!c->brute && c->accel.nNodes && (leafMax == 0 ? PT_LEAF_DEFAULT : leafMax) <= 7 && !getenv("PT_NO_QUADS"))
 	{
 		// scenes made of quad faces: two-triangle fan leaves become quad leaves for k_paths (pt_build.h)
-		hipError_t qe = ptBuildQuadLeaves(c->accel.nodes, c->accel.nNodes, c->accel.tris, c->accel.nTris, 0.9f, c->quadAccel, c->stream);
+		hipError_t qe = ptBuildQuadLeaves(c->accel.nodes, c->accel.nNodes, c->accel.tris + (size_t)(c->accel.triPlanes - 1) * c->accel.nTris,
+		                                  c->accel.nTris, 0.9f, c->quadAccel, c->stream);
 		if (qe != hipSuccess)
 		{
 			freeAccel(c);
@@ -890,7 +901,8 @@ extern "C" int pt_build_accel(pt_ctx *c, int flags) try
 		// a ray (of the node array k_paths traverses)
 		const bool two = c->tlasDepth != 0;
 		hipError_t ee = ptBuildEntryNode(c->quadAccel.nQuads ? c->quadAccel.nodes : c->accel.nodes, c->accel.nNodes, two ? c->tlasRoot : 0u,
-		                                 c->accel.tris, c->accel.nTris, c->quadAccel.quads, c->quadAccel.nQuads, two, &c->dEntry,
+		                                 c->accel.tris + (size_t)(c->accel.triPlanes - 1) * c->accel.nTris, c->accel.nTris, c->quadAccel.quads,
+		                                 c->quadAccel.nQuads, two, &c->dEntry,
 		                                 &c->entryFlat, c->stream);
 		if (getenv("PT_NO_FLAT")) c->entryFlat = false;
 		if (ee != hipSuccess)
@@ -1835,6 +1847,6 @@ extern "C" int pt_debug_read_bvh(pt_ctx *c, void *nodes, uint32_t *nNodes, void 
 	if (nodes && c->accel.nNodes)
 		PT_HIP(c, hipMemcpy(nodes, c->accel.nodes, sizeof(PtNode4) * (size_t)c->accel.nNodes, hipMemcpyDeviceToHost));
 	if (tris && c->accel.nTris)
-		PT_HIP(c, hipMemcpy(tris, c->accel.tris + 2 * (size_t)c->accel.nTris, sizeof(PtTri48) * (size_t)c->accel.nTris, hipMemcpyDeviceToHost));
+		PT_HIP(c, hipMemcpy(tris, c->accel.tris + (size_t)(c->accel.triPlanes - 1) * c->accel.nTris, sizeof(PtTri48) * (size_t)c->accel.nTris, hipMemcpyDeviceToHost));
 	return PT_OK;
 }

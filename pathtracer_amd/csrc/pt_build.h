@@ -18,12 +18,18 @@ struct PtBuildInput
 	const float4 *boxLo = nullptr, *boxHi = nullptr;
 	uint32_t nodeBase = 0;
 	int padExp = 18;
+	// leaf triangle records: 3 = once per dominant ray axis (coordinates rotated, DESIGN.md 3: nothing per triangle in the
+	// traversal), 1 = the identity plane only (the traversal permutes with selects): a third of the bytes to write and keep,
+	// for scenes whose traversal waits for HBM anyway
+	int triPlanes = 3;
 };
 
 struct PtBuildOutput
 {
 	PtNode4 *nodes = nullptr;   // device, nNodes used
-	PtTri48 *tris = nullptr;    // device, 3 planes x nTris, leaf order; plane r = coordinates rotated to ((r+1)%3,(r+2)%3,r)
+	PtTri48 *tris = nullptr;    // device, triPlanes planes x nTris, leaf order; plane r = coordinates rotated to ((r+1)%3,(r+2)%3,r);
+	                            // the identity plane (x, y, z) is the LAST one: plane 2 of three, or the only one
+	int triPlanes = 3;
 	uint32_t *codes = nullptr;  // device, Morton code per primitive (primitive order)
 	uint32_t *order = nullptr;  // device, primitive ids sorted by (code, id)
 	uint32_t nNodes = 0, nTris = 0, depth = 0;
@@ -44,6 +50,7 @@ struct PtQuadOutput
 	PtQuad64 *quads = nullptr;   // device, 3 planes x nQuads
 	uint32_t nQuads = 0;
 };
+// (tris: the IDENTITY plane of the triangle records)
 hipError_t ptBuildQuadLeaves(const PtNode4 *nodes, uint32_t nNodes, const PtTri48 *tris, uint32_t nTris, float minShare,
                              PtQuadOutput &out, hipStream_t stream);
 
@@ -53,6 +60,7 @@ hipError_t ptBuildQuadLeaves(const PtNode4 *nodes, uint32_t nNodes, const PtTri4
 // boxes of their triangles / quads -- unless instanceLeaves: `root` is the root of a top-level tree, whose leaves are
 // instances and keep the tree's boxes.  *flat: every child is a triangle leaf (the node is the whole scene).  Synchronises
 // the stream.  The caller owns the allocation.
+// (tris: the IDENTITY plane of the triangle records)
 hipError_t ptBuildEntryNode(const PtNode4 *nodes, uint32_t nNodes, uint32_t root, const PtTri48 *tris, uint32_t nTris,
                             const PtQuad64 *quads, uint32_t nQuads, bool instanceLeaves, uint4 **rec, bool *flat, hipStream_t stream);
 

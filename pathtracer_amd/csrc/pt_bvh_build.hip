@@ -533,7 +533,7 @@ __device__ __forceinline__ void loadBox(const float *src, float lo[3], float hi[
 __global__ void __launch_bounds__(kBlock) k_refit(const float4 *triPos, const float4 *triLo, const float4 *triHi,
                                                   const uint32_t *sortedPrim, int n, const int4 *topo, const int *leafParent,
                                                   const int *bounds, float *boxes, unsigned int *arrive, float padScale,
-                                                  PtTri48 *tris)
+                                                  PtTri48 *tris, int planes)
 {
 	__shared__ float sBox[6][2 * kBlock];  // slot: internal node i -> i - base, leaf k -> kBlock + k - base
 	__shared__ unsigned int sArrive[kBlock];
@@ -565,12 +565,13 @@ __global__ void __launch_bounds__(kBlock) k_refit(const float4 *triPos, const fl
 #pragma unroll
 		for (int r = 0; r < 3; ++r)
 		{
+			if (planes == 1 && r != 2) continue;  // (uniform) one plane: the identity
 			const int x = (r + 1) % 3, y = (r + 2) % 3, z = r;
 			stage[3 * threadIdx.x + 0] = make_float4(q[0][x], q[0][y], q[0][z], q[1][x]);
 			stage[3 * threadIdx.x + 1] = make_float4(q[1][y], q[1][z], q[2][x], q[2][y]);
 			stage[3 * threadIdx.x + 2] = make_float4(q[2][z], __uint_as_float(prim), 0.0f, 0.0f);
 			__syncthreads();
-			float4 *dst = reinterpret_cast<float4 *>(tris + (size_t)r * n + base);
+			float4 *dst = reinterpret_cast<float4 *>(tris + (planes == 1 ? (size_t)0 : (size_t)r * n) + base);
 			for (int i = threadIdx.x; i < 3 * nRec; i += kBlock) dst[i] = stage[i];
 			__syncthreads();
 		}
@@ -942,7 +943,7 @@ __global__ void __launch_bounds__(kBlock)
 // selects (plane 2 is the identity).  One thread per slot: three 16-byte stores per plane, consecutive lanes write
 // consecutive 48-byte records.
 __global__ void __launch_bounds__(kBlock) k_write_tris(const uint32_t *leafPrim, uint32_t n, const float4 *triPos,
-                                                       PtTri48 *tris)
+                                                       PtTri48 *tris, int planes)
 {
 	uint32_t j = blockIdx.x * kBlock + threadIdx.x;
 	if (j >= n) return;
@@ -952,8 +953,9 @@ __global__ void __launch_bounds__(kBlock) k_write_tris(const uint32_t *leafPrim,
 #pragma unroll
 	for (int r = 0; r < 3; ++r)
 	{
+		if (planes == 1 && r != 2) continue;  // one plane: the identity
 		const int x = (r + 1) % 3, y = (r + 2) % 3, z = r;
-		float4 *dst = reinterpret_cast<float4 *>(tris + (size_t)r * n + j);
+		float4 *dst = reinterpret_cast<float4 *>(tris + (planes == 1 ? (size_t)0 : (size_t)r * n) + j);
 		dst[0] = make_float4(a[x], a[y], a[z], b[x]);
 		dst[1] = make_float4(b[y], b[z], c[x], c[y]);
 		dst[2] = make_float4(c[z], __uint_as_float(prim), 0.0f, 0.0f);
@@ -1164,7 +1166,8 @@ hipError_t ptBuildBvh4(const PtBuildInput &in, PtBuildOutput &out, hipStream_t s
 	PtTri48 *tris = nullptr;
 	uint32_t *codes = nullptr, *order = nullptr;
 	TRY(hipMalloc(&nodes, sizeof(PtNode4) * (size_t)n));  // a wide node has >= 2 children unless it is the root
-	if (!boxMode) TRY(hipMalloc(&tris, 3 * sizeof(PtTri48) * (size_t)n));  // three axis-rotated planes
+	const int planes = in.triPlanes == 1 ? 1 : 3;
+	if (!boxMode) TRY(hipMalloc(&tris, (size_t)planes * sizeof(PtTri48) * (size_t)n));  // three axis-rotated planes, or the identity
 	TRY(hipMalloc(&codes, 4 * (size_t)n));
 	TRY(hipMalloc(&order, 4 * (size_t)n));
 
@@ -1203,7 +1206,7 @@ hipError_t ptBuildBvh4(const PtBuildInput &in, PtBuildOutput &out, hipStream_t s
 			// sorted order, so the thread that gathers a primitive's positions for its box writes its three records too
 			static const int refitPad = getenv("PT_REFIT_LDS_PAD") ? atoi(getenv("PT_REFIT_LDS_PAD")) : 0;  // tuning: occupancy limiter
 			k_refit<<<gridTris, kBlock, (size_t)refitPad, stream>>>(boxMode ? nullptr : triPos, triLo, triHi, vin, (int)n, topo, leafParent, bounds,
-			                                         boxes, arrive, padScale, tris);
+			                                         boxes, arrive, padScale, tris, planes);
 		}
 		if (err == hipSuccess && ploc)
 		{
@@ -1251,7 +1254,7 @@ hipError_t ptBuildBvh4(const PtBuildInput &in, PtBuildOutput &out, hipStream_t s
 				const uint32_t cap = level < 10 ? divUp((size_t)1 << (2 * level), kBlock) : grid;
 				k_collapse_level<<<cap < grid ? cap : grid, kBlock, 0, stream>>>(tin, tout, counters + 8, level, view, boxes, vin, boxMode,
 				                                                                 leafPrim, nodes, counters + 1, leafMax, in.nodeBase,
-				                                                                 (!ploc && !boxMode) ? tris + 2 * (size_t)n : nullptr, bounds, padScale);
+				                                                                 (!ploc && !boxMode) ? tris + (size_t)(planes - 1) * n : nullptr, bounds, padScale);
 				CollapseTask *t = tin;
 				tin = tout;
 				tout = t;
@@ -1271,7 +1274,7 @@ hipError_t ptBuildBvh4(const PtBuildInput &in, PtBuildOutput &out, hipStream_t s
 				if (h[1] > n || nodeCount > n) err = hipErrorAssert;
 			}
 		}
-		if (err == hipSuccess && leafPrim) k_write_tris<<<gridTris, kBlock, 0, stream>>>(leafPrim, n, triPos, tris);
+		if (err == hipSuccess && leafPrim) k_write_tris<<<gridTris, kBlock, 0, stream>>>(leafPrim, n, triPos, tris, planes);
 		TRY(hipGetLastError());
 	}
 	if (err == hipSuccess)
@@ -1298,6 +1301,7 @@ hipError_t ptBuildBvh4(const PtBuildInput &in, PtBuildOutput &out, hipStream_t s
 	out.order = order;
 	out.nNodes = nodeCount;
 	out.nTris = n;
+	out.triPlanes = planes;
 	out.depth = depth;
 	return hipSuccess;
 }
@@ -1372,7 +1376,7 @@ __global__ void __launch_bounds__(kBlock) k_quad_sample(const PtNode4 *nodes, ui
 // index = exclusive scan of the flags.  Writes the quad records (all three planes, from the triangle records of the same
 // plane) and patches the child reference in the copy of the node array.
 __global__ void __launch_bounds__(kBlock)
-    k_quad_write(const PtNode4 *nodes, uint32_t nNodes, const PtTri48 *tris, uint32_t nTris, const uint32_t *index,
+    k_quad_write(const PtNode4 *nodes, uint32_t nNodes, const PtTri48 *plane2, const uint32_t *index,
                  PtNode4 *nodesOut, PtQuad64 *quads, uint32_t nQuads)
 {
 	const uint32_t i = blockIdx.x * kBlock + threadIdx.x;
@@ -1380,22 +1384,24 @@ __global__ void __launch_bounds__(kBlock)
 	const uint32_t ref = nodes[i >> 2].child[i & 3u];
 	if (!quadCandidate(ref)) return;
 	const uint32_t first = ref & 0x0FFFFFFFu;
-	const PtTri48 *plane2 = tris + 2 * (size_t)nTris;
 	const int pat = quadPattern(plane2[first], plane2[first + 1]);
 	if (pat == 0) return;
 	const uint32_t qi = index[i];
 	if (qi >= nQuads) return;  // cannot happen (the scan counted exactly these slots); keeps a wrong count from writing outside
 	const uint32_t ia = pat == 1 ? first : first + 1, ib = pat == 1 ? first + 1 : first;
+	// the quad's three rotated records from the triangles' identity records (plane r holds the coordinates ((r+1)%3,
+	// (r+2)%3, r), as the triangle planes do): the same values whether the scene keeps three triangle planes or one
+	const PtTri48 a = plane2[ia], b = plane2[ib];
 	for (int r = 0; r < 3; ++r)
 	{
-		const PtTri48 a = tris[(size_t)r * nTris + ia], b = tris[(size_t)r * nTris + ib];
+		const int ax[3] = { (r + 1) % 3, (r + 2) % 3, r };
 		PtQuad64 q;
 		for (int k = 0; k < 3; ++k)
 		{
-			q.v0[k] = a.v0[k];
-			q.v1[k] = a.v1[k];
-			q.v2[k] = a.v2[k];
-			q.v3[k] = b.v2[k];
+			q.v0[k] = a.v0[ax[k]];
+			q.v1[k] = a.v1[ax[k]];
+			q.v2[k] = a.v2[ax[k]];
+			q.v3[k] = b.v2[ax[k]];
 		}
 		q.primA = a.prim;
 		q.primB = b.prim;
@@ -1425,7 +1431,7 @@ hipError_t ptBuildQuadLeaves(const PtNode4 *nodes, uint32_t nNodes, const PtTri4
 		if (e == hipSuccess) e = hipMemsetAsync(count, 0, sizeof(h), stream);
 		if (e == hipSuccess)
 		{
-			k_quad_sample<<<divUp(4u * kSample, kBlock), kBlock, 0, stream>>>(nodes, nNodes - kSample, kSample, tris + 2 * (size_t)nTris, count);
+			k_quad_sample<<<divUp(4u * kSample, kBlock), kBlock, 0, stream>>>(nodes, nNodes - kSample, kSample, tris, count);
 			e = hipMemcpyAsync(h, count, sizeof(h), hipMemcpyDeviceToHost, stream);
 		}
 		if (e == hipSuccess) e = hipStreamSynchronize(stream);
@@ -1436,7 +1442,7 @@ hipError_t ptBuildQuadLeaves(const PtNode4 *nodes, uint32_t nNodes, const PtTri4
 	e = hipMalloc(&flags, 4 * words);
 	if (e != hipSuccess) return e;
 	uint32_t *scratch = flags + ((nSlots + 63) & ~(size_t)63), *total = flags + words - 64;
-	k_quad_flag<<<divUp((uint32_t)nSlots, kBlock), kBlock, 0, stream>>>(nodes, nNodes, tris + 2 * (size_t)nTris, flags);
+	k_quad_flag<<<divUp((uint32_t)nSlots, kBlock), kBlock, 0, stream>>>(nodes, nNodes, tris, flags);
 	scanExclusive<uint32_t>(flags, nSlots, scratch, total, stream);  // the grand total comes out of the top level of the recursion
 	uint32_t nQuads = 0;
 	e = hipMemcpyAsync(&nQuads, total, 4, hipMemcpyDeviceToHost, stream);
@@ -1448,8 +1454,7 @@ hipError_t ptBuildQuadLeaves(const PtNode4 *nodes, uint32_t nNodes, const PtTri4
 		if (e == hipSuccess) e = hipMemcpyAsync(out.nodes, nodes, sizeof(PtNode4) * (size_t)nNodes, hipMemcpyDeviceToDevice, stream);
 		if (e == hipSuccess)
 		{
-			k_quad_write<<<divUp((uint32_t)nSlots, kBlock), kBlock, 0, stream>>>(nodes, nNodes, tris, nTris, flags, out.nodes, out.quads,
-			                                                                  nQuads);
+			k_quad_write<<<divUp((uint32_t)nSlots, kBlock), kBlock, 0, stream>>>(nodes, nNodes, tris, flags, out.nodes, out.quads, nQuads);
 			e = hipStreamSynchronize(stream);
 		}
 		if (e == hipSuccess) e = hipGetLastError();
@@ -1668,7 +1673,7 @@ hipError_t ptBuildEntryNode(const PtNode4 *nodes, uint32_t nNodes, uint32_t root
 	uint4 *d = nullptr;
 	hipError_t e = hipMalloc(&d, sizeof(uint4) * PT_ENTRY_REC);
 	if (e != hipSuccess) return e;
-	k_entry_node<<<1, 64, 0, stream>>>(nodes, nNodes, root, tris + 2 * (size_t)nTris, nQuads ? quads + 2 * (size_t)nQuads : nullptr,
+	k_entry_node<<<1, 64, 0, stream>>>(nodes, nNodes, root, tris, nQuads ? quads + 2 * (size_t)nQuads : nullptr,
 	                                   instanceLeaves, reinterpret_cast<float4 *>(d));
 	e = hipGetLastError();
 	uint32_t head[8] = {};

@@ -428,7 +428,7 @@ struct PtSceneDev
 	const uint32_t *matIndices;
 	const PtShadeRec *shade;  // per-primitive shading records (nullptr: gather as raytrace.rchit does)
 	const PtNode4 *nodes;
-	const PtTri48 *tris;
+	const PtTri48 *tris;  // triPlanes planes of nTris records; the identity plane is the last
 	uint32_t nTris;
 	uint32_t nNodes;
 	const PtQuad64 *quads;  // quad leaves (three planes of nQuads records, rotated like tris) or nullptr
@@ -436,6 +436,7 @@ struct PtSceneDev
 	// optional diffuse map (pt_set_texture): texW x texH linear RGBA texels, row 0 = v 0; nullptr = none
 	const float4 *texture;
 	uint32_t texW, texH;
+	uint32_t triPlanes;  // 3 (one plane per dominant ray axis) or 1 (identity only: the leaf test permutes with selects)
 };
 
 // Diffuse map lookup (no counterpart in the reference's shaders, which never sample textures/viking_room.png:

@@ -119,7 +119,7 @@ __device__ __forceinline__ PtHit traverseBvh4(const PtSceneDev &sc, float3x o, f
 			if (kStats) triTests += cnt;
 			for (uint32_t i = 0; i < cnt; ++i)
 			{
-				const float4 *tp = reinterpret_cast<const float4 *>(sc.tris + 2 * (size_t)sc.nTris + first + i);  // identity plane
+				const float4 *tp = reinterpret_cast<const float4 *>(sc.tris + (size_t)(sc.triPlanes - 1u) * sc.nTris + first + i);  // identity plane
 				float4 a = tp[0], b = tp[1], c = tp[2];
 				float3x p0 = { a.x, a.y, a.z }, p1 = { a.w, b.x, b.y }, p2 = { b.z, b.w, c.x };
 				pt_tri_test(o, rs, tmin, p0, p1, p2, __float_as_uint(c.y), best);

@@ -461,10 +461,27 @@ __device__ __forceinline__ void pt_leaf_test(const PtSceneDev &sc, const PtLaneR
 		{
 			uint32_t cnt = ((cur >> 28) & 7u) + 1u;
 			triTests += cnt;
-			const float4 *tp = reinterpret_cast<const float4 *>(sc.tris + (size_t)kz * sc.nTris + first);
+			// three planes: the record of the ray's dominant axis holds the coordinates in (kx, ky, kz) order already; one plane
+			// (big scenes, whose traversal waits for memory: a third of the bytes built and kept): permuted here (wave-uniform test)
+			const bool onePlane = sc.triPlanes == 1u;
+			const float4 *tp = reinterpret_cast<const float4 *>(sc.tris + (onePlane ? (size_t)0 : (size_t)kz * sc.nTris) + first);
 			for (uint32_t i = 0; i < cnt; ++i, tp += 3)
 			{
 				float4 a = tp[0], b = tp[1], c = tp[2];
+				if (onePlane)
+				{
+					// (x y z x) (y z x y) (z prim - -)  ->  vertex j as (kx, ky, kz)
+					const float v0x = a.x, v0y = a.y, v0z = a.z, v1x = a.w, v1y = b.x, v1z = b.y, v2x = b.z, v2y = b.w, v2z = c.x;
+					a.x = kz == 0 ? v0y : (kz == 1 ? v0z : v0x);
+					a.y = kz == 0 ? v0z : (kz == 1 ? v0x : v0y);
+					a.z = kz == 0 ? v0x : (kz == 1 ? v0y : v0z);
+					a.w = kz == 0 ? v1y : (kz == 1 ? v1z : v1x);
+					b.x = kz == 0 ? v1z : (kz == 1 ? v1x : v1y);
+					b.y = kz == 0 ? v1x : (kz == 1 ? v1y : v1z);
+					b.z = kz == 0 ? v2y : (kz == 1 ? v2z : v2x);
+					b.w = kz == 0 ? v2z : (kz == 1 ? v2x : v2y);
+					c.x = kz == 0 ? v2x : (kz == 1 ? v2y : v2z);
+				}
 				float Akx = a.x - rox, Aky = a.y - roy, Akz = a.z - roz;
 				float Bkx = a.w - rox, Bky = b.x - roy, Bkz = b.y - roz;
 				float Ckx = b.z - rox, Cky = b.w - roy, Ckz = c.x - roz;

@@ -20,7 +20,7 @@ if os.environ.get("AB_SPP"): a.spp_per_frame = int(os.environ["AB_SPP"])
 sc, view, proj, tmax, name = bench.build_scene(a, pa)
 rt = pa.HipRaytracing(0)
 if a.instances is not None: rt.setInstances(a.instances)
-rt.buildBlas(sc, pa.api.PT_ACCEL_BVH4 if scene.startswith("soup") else pa.api.PT_ACCEL_BVH4_PLOC); rt.buildTlas()
+rt.buildBlas(sc, (pa.api.PT_ACCEL_BVH4 if scene.startswith("soup") else pa.api.PT_ACCEL_BVH4_PLOC) | int(os.environ.get("AB_ACCEL_FLAGS", "0"), 0)); rt.buildTlas()
 if a.texture is not None: rt.setTexture(a.texture)
 rt.resize(a.width, a.height); rt.setCamera(view, proj)
 rt.setParams(spp_per_frame=a.spp_per_frame, max_depth=a.depth, tmin=1e-3, tmax=tmax, seed=0, max_frames=0)

@@ -286,3 +286,47 @@ def test_quad_leaves_of_a_big_scene_pass_the_sampled_check(rt, pa):
     rt.buildBlas(soup, BUILDERS["lbvh"])
     st = rt.stats()
     assert st.bvh_nodes > (1 << 19) and st.quad_leaves == 0
+
+
+@pytest.mark.parametrize("builder", sorted(BUILDERS))
+def test_one_triangle_plane_equals_three(rt, pa, O, builder):
+    """PT_ACCEL_TRI_PLANES_1 (what one Model of 2 M triangles or more gets by itself): the leaf triangles are stored once, in
+    x, y, z order, and the leaf test permutes them -- a third of the bytes, the same hits bit for bit (incoherent rays against
+    brute force and against the three-plane build), the same image and ray count in all three pipelines."""
+    from pathtracer_amd.api import PT_ACCEL_TRI_PLANES_1, PT_ACCEL_TRI_PLANES_3
+    sc = pa.scenes.with_light_quad(pa.scenes.grid_mesh(37, 29, size=2.0, height=0.2, amplitude=0.3),
+                                   [[-0.5, 1.5, -0.5], [0.5, 1.5, -0.5], [0.5, 1.5, 0.5], [-0.5, 1.5, 0.5]], (0, -1, 0))
+    osc = O.OracleScene(sc.vertices, sc.indices, sc.materials, sc.mat_indices)
+    rng = np.random.default_rng(8)
+    rays = np.zeros((20000, 6), dtype=np.float32)
+    rays[:, :3] = rng.uniform(-1.2, 1.2, (20000, 3)) + (0, 0.8, 0)
+    d = rng.normal(size=(20000, 3))
+    rays[:, 3:] = d / np.linalg.norm(d, axis=1, keepdims=True)
+    want_hits = osc.trace(rays, brute=True)
+    W, H = 96, 64
+    view = pa.look_at((0.2, 1.3, 2.4), (0.0, 0.2, 0.0), (0, 1, 0))
+    proj = pa.perspective(np.radians(50.0), W / H, 0.1, 100.0)
+    proj[5] *= -1
+    want, nrays = osc.render(view, proj, W, H, frames=2, spp_per_frame=3, max_depth=6, seed=5)
+    sizes = {}
+    for planes in (PT_ACCEL_TRI_PLANES_3, PT_ACCEL_TRI_PLANES_1):
+        rt.buildBlas(sc, BUILDERS[builder] | planes)
+        st = rt.stats()
+        sizes[planes] = st.accel_bytes
+        assert np.array_equal(rt.debugTrace(rays).view(np.uint32), want_hits.view(np.uint32))
+        nodes, tris = rt.debugReadBvh()
+        assert len(tris) == sc.n_tris and sorted(tris["prim"].tolist()) == list(range(sc.n_tris))
+        rt.resize(W, H)
+        rt.setCamera(view, proj)
+        rt.setParams(spp_per_frame=3, max_depth=6, seed=5)
+        for mode in (2, 0, 1):
+            rt.setPipeline(mode)
+            rt.resetFrame()
+            rt.resetStats()
+            rt.raytrace(2)
+            assert rt.stats().rays_total == nrays
+            assert np.array_equal(bits(rt.readImage()), bits(want)), (planes, mode)
+        rt.setPipeline(2)
+    assert sizes[PT_ACCEL_TRI_PLANES_3] - sizes[PT_ACCEL_TRI_PLANES_1] == 2 * 48 * sc.n_tris
+    with pytest.raises(pa.PathTracerError):
+        rt.buildBlas(sc, BUILDERS[builder] | PT_ACCEL_TRI_PLANES_1 | PT_ACCEL_TRI_PLANES_3)
