@@ -181,6 +181,15 @@ __global__ void __launch_bounds__(kBlock) k_morton(const float4 *triLo, const fl
 // order and the scatter is stable.
 constexpr int kItems = 8;
 constexpr int kTile = kBlock * kItems;
+// A block sorts kSuper consecutive tiles one after the other, carrying the running digit offsets in LDS, so the histogram
+// array -- and the scan over it -- has one entry per digit and SUPER tile: at 100 M keys 1.5 M counters per pass instead of
+// 12.5 M (whose strided 4-byte stores cost the histogram kernel 1.6 GB of partial-line writes, profiles/r03m, and whose scan
+// cost as much again as the histogram).
+#ifndef PT_SORT_SUPER
+#define PT_SORT_SUPER 8
+#endif
+constexpr int kSuper = PT_SORT_SUPER;
+constexpr int kSuperTile = kTile * kSuper;
 constexpr int kRadixBits = 8;   // measured at 100 M keys: 10-bit digits (3 passes) scatter 2 keys per digit and tile -- 1.85 ms a pass against 1.0
 constexpr int kRadixBins = 1 << kRadixBits;
 constexpr int kSortBits = 32;  // bits of the key that are sorted (30-bit Morton codes: four 8-bit passes)
@@ -191,9 +200,9 @@ __global__ void __launch_bounds__(kBlock) k_radix_hist(const uint32_t *keys, uin
 	__shared__ uint32_t bins[kRadixBins];
 	for (int i = threadIdx.x; i < kRadixBins; i += kBlock) bins[i] = 0;
 	__syncthreads();
-	size_t base = (size_t)blockIdx.x * kTile;
-#pragma unroll
-	for (int r = 0; r < kItems; ++r)
+	size_t base = (size_t)blockIdx.x * kSuperTile;
+#pragma unroll 8
+	for (int r = 0; r < kItems * kSuper; ++r)
 	{
 		size_t i = base + r * kBlock + threadIdx.x;
 		if (i < n) atomicAdd(&bins[(keys[i] >> shift) & (uint32_t)(kRadixBins - 1)], 1u);
@@ -318,12 +327,18 @@ __global__ void __launch_bounds__(kBlock) k_radix_scatter(const uint32_t *keysIn
 	__shared__ uint32_t digitBase[kRadixBins], tileStart[kRadixBins], sScan[kBlock / PT_WAVE];
 	__shared__ uint32_t sKey[kTile], sVal[kTile];
 	const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+	const unsigned long long lanesBelow = (1ull << lane) - 1ull;
+	static_assert(kRadixBins == kBlock, "one digit per thread below");
+	digitBase[threadIdx.x] = histScanned[(size_t)threadIdx.x * nBlocks + blockIdx.x];  // first output position of digit d of this super tile
+	for (int sub = 0; sub < kSuper; ++sub)
+	{
+	const size_t tileBase = (size_t)blockIdx.x * kSuperTile + (size_t)sub * kTile;
+	if (tileBase >= n) break;  // (uniform)
 	for (int i = threadIdx.x; i < kWaves * kRadixBins; i += kBlock) (&waveCount[0][0])[i] = 0;
 	__syncthreads();
 
 	uint32_t key[kItems], val[kItems], rank[kItems];
-	const size_t waveBase = (size_t)blockIdx.x * kTile + (size_t)wave * (kItems * PT_WAVE);
-	const unsigned long long lanesBelow = (1ull << lane) - 1ull;
+	const size_t waveBase = tileBase + (size_t)wave * (kItems * PT_WAVE);
 #pragma unroll
 	for (int r = 0; r < kItems; ++r)
 	{
@@ -348,7 +363,6 @@ __global__ void __launch_bounds__(kBlock) k_radix_scatter(const uint32_t *keysIn
 	}
 	__syncthreads();
 	// per digit: exclusive scan across the waves of the block, and the digit's total in this tile
-	static_assert(kRadixBins == kBlock, "one digit per thread below");
 	uint32_t digitTotal;
 	{
 		const int d = threadIdx.x;
@@ -360,7 +374,6 @@ __global__ void __launch_bounds__(kBlock) k_radix_scatter(const uint32_t *keysIn
 			run += c;
 		}
 		digitTotal = run;
-		digitBase[d] = histScanned[(size_t)d * nBlocks + blockIdx.x];
 	}
 	// Position of every key inside the tile once the tile is sorted by digit (stable): the keys go through LDS in that
 	// order, so that consecutive lanes then store consecutive addresses of one digit's run -- a wave store touches ~9 runs
@@ -394,14 +407,19 @@ __global__ void __launch_bounds__(kBlock) k_radix_scatter(const uint32_t *keysIn
 			valsOut[dst] = sVal[pos];
 		}
 	}
+	__syncthreads();  // every thread has read digitBase and the staging area
+	digitBase[threadIdx.x] += digitTotal;  // the next tile of this block continues behind this one's keys, digit by digit
+	}
 }
 
 // ----------------------------------------------------------------- LBVH topology ----
 // BVH2 node numbering: internal nodes 0 .. n-2, leaf for sorted position k is (n-1) + k.
-__device__ __forceinline__ int lbvhDelta(const uint32_t *keys, int n, int i, int j)
+// delta(i, j) of Karras 2012 over the sorted keys: common leading bits, the index as a tie-break; -1 outside the array.
+// `at` reads a key by position.
+template <typename KeyAt> __device__ __forceinline__ int lbvhDelta(const KeyAt &at, int n, uint32_t a, int i, int j)
 {
 	if (j < 0 || j >= n) return -1;
-	uint32_t a = keys[i], b = keys[j];
+	const uint32_t b = at(j);
 	if (a == b) return 32 + __clz((uint32_t)i ^ (uint32_t)j);
 	return __clz(a ^ b);
 }
@@ -411,25 +429,41 @@ __device__ __forceinline__ int lbvhDelta(const uint32_t *keys, int n, int i, int
 // the refit walk reads ONE record per level (children, range for the LDS test, next parent) where three arrays cost it
 // three dependent loads.  The parent word of record c is written by c's parent's thread, the other three by c's own:
 // separate stores to separate words, no conflict.  leafParent[k] = parent of the leaf at sorted position k.
+// The searches of a node read keys near its own position -- a node's range is short for all but the top of the tree -- so the
+// block keeps the keys of its 256 positions and of 256 either side in LDS (3 KB) and only the long ranges go to memory: the
+// kernel was a chain of dependent loads (2.5 ms at 100 M keys, 1.3 TB/s of traffic).
 __global__ void __launch_bounds__(kBlock) k_lbvh_topology(const uint32_t *keys, int n, int4 *topo, int *leafParent)
 {
+	__shared__ uint32_t sKeys[3 * kBlock];
+	const int winFirst = (int)(blockIdx.x * kBlock) - kBlock;  // position of sKeys[0]
+	for (int k = threadIdx.x; k < 3 * kBlock; k += kBlock)
+	{
+		const int pos = winFirst + k;
+		sKeys[k] = (pos >= 0 && pos < n) ? keys[pos] : 0u;
+	}
+	__syncthreads();
 	int i = blockIdx.x * kBlock + threadIdx.x;
 	if (i >= n - 1) return;
-	int d = (lbvhDelta(keys, n, i, i + 1) - lbvhDelta(keys, n, i, i - 1)) >= 0 ? 1 : -1;
-	int dmin = lbvhDelta(keys, n, i, i - d);
+	auto at = [&](int j) -> uint32_t {
+		const int k = j - winFirst;
+		return (k >= 0 && k < 3 * kBlock) ? sKeys[k] : keys[j];
+	};
+	const uint32_t a = sKeys[kBlock + threadIdx.x];
+	int d = (lbvhDelta(at, n, a, i, i + 1) - lbvhDelta(at, n, a, i, i - 1)) >= 0 ? 1 : -1;
+	int dmin = lbvhDelta(at, n, a, i, i - d);
 	int lmax = 2;
-	while (lbvhDelta(keys, n, i, i + lmax * d) > dmin) lmax <<= 1;
+	while (lbvhDelta(at, n, a, i, i + lmax * d) > dmin) lmax <<= 1;
 	int l = 0;
 	for (int t = lmax >> 1; t >= 1; t >>= 1)
-		if (lbvhDelta(keys, n, i, i + (l + t) * d) > dmin) l += t;
+		if (lbvhDelta(at, n, a, i, i + (l + t) * d) > dmin) l += t;
 	int j = i + l * d;
-	int dnode = lbvhDelta(keys, n, i, j);
+	int dnode = lbvhDelta(at, n, a, i, j);
 	int s = 0;
 	int t = l;
 	do
 	{
 		t = (t + 1) >> 1;
-		if (lbvhDelta(keys, n, i, i + (s + t) * d) > dnode) s += t;
+		if (lbvhDelta(at, n, a, i, i + (s + t) * d) > dnode) s += t;
 	} while (t > 1);
 	int gamma = i + s * d + (d < 0 ? d : 0);
 	int first = i < j ? i : j, last = i < j ? j : i;
@@ -1113,7 +1147,7 @@ hipError_t ptBuildBvh4(const PtBuildInput &in, PtBuildOutput &out, hipStream_t s
 
 	// ---- scratch: ONE allocation carved into 256-byte aligned pieces (hipMalloc/hipFree of two dozen multi-GB
 	// buffers cost more than the build itself), freed on exit ----
-	const uint32_t nSortBlocks = divUp(n, kTile);
+	const uint32_t nSortBlocks = divUp(n, kSuperTile);
 	const size_t histLen = (size_t)kRadixBins * nSortBlocks;
 	const size_t nNodes2 = 2 * (size_t)n - 1;
 	const uint32_t plocBlocks = divUp(n, kBlock);
