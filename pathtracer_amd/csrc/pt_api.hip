@@ -1174,7 +1174,7 @@ int renderPersistent(pt_ctx *c, int n, bool noAlloc = false)
 	if (noAlloc) budget = 2 * kNaRecBytes;
 	if (perLaunch * nPadded * pathBytes > budget) perLaunch = budget / (nPadded * pathBytes);
 	if (perLaunch < 1) perLaunch = 1;
-	const size_t firstRequest = nPadded * (n > 1 ? perLaunch : (size_t)1);  // (what the loop below asks ensurePersistent for)
+	const size_t firstRequest = nPadded * (n > 1 ? 2 * perLaunch - 1 : (size_t)1);  // (at most what the loop below asks ensurePersistent for)
 	if (!noAlloc && (firstRequest > c->pCap || (!ringOnly && firstRequest > c->pStateCap)))
 	{
 		// the buffers will have to grow (only then is the driver asked): never plan for more than half of what the device has
@@ -1189,6 +1189,11 @@ int renderPersistent(pt_ctx *c, int n, bool noAlloc = false)
 		}
 	}
 	if (nPadded > 0xFFFFFF00ull) return fail(c, PT_EINVAL, "pt_render_frame: %zu paths per frame exceed 2^32", nPadded);
+	// frames ONE launch may hold at most (budget and path ids): a call that ends with less than a full launch beyond a full one
+	// runs them together -- 20 frames are one launch of 20, not 16 + 4, where the short launch pays the whole drain (~0.3 ms)
+	// for a quarter of the frames
+	size_t maxFit = budget / (nPadded * pathBytes);
+	if (maxFit * nPadded > 0xFFFFFF00ull) maxFit = 0xFFFFFF00ull / nPadded;
 	hipStream_t s = c->stream;
 	int rc = PT_OK;
 	float4 *state = nullptr, *rad = nullptr, *ringO = nullptr, *ringD = nullptr;
@@ -1231,16 +1236,21 @@ int renderPersistent(pt_ctx *c, int n, bool noAlloc = false)
 	while (n > 0)
 	{
 		uint32_t batch = (uint32_t)((size_t)n < perLaunch ? (size_t)n : perLaunch);
+		if (!noAlloc && (size_t)n > perLaunch && (size_t)n < 2 * perLaunch && (size_t)n <= maxFit) batch = (uint32_t)n;
 		// a multi-frame call sizes the buffers for full launches at once, so that a later, longer call (warm-up of 4 frames,
 		// then 64) does not reallocate 8 GB in the middle of a render; frame-by-frame callers keep a one-frame buffer
 		// (a second context on the GPU, or a 4K frame, may leave less room than the budget: halve and try again)
 		if (!noAlloc)
 		{
 			bool oom = false;
-			rc = ensurePersistent(c, nPadded * (n > 1 ? perLaunch : (size_t)batch), flatScene, &oom);
+			// (a multi-frame call sizes them for the longest launch a later call may make: a stretched one)
+			size_t longest = 2 * perLaunch - 1 < maxFit ? 2 * perLaunch - 1 : maxFit;
+			if (longest < batch) longest = batch;
+			rc = ensurePersistent(c, nPadded * (n > 1 ? longest : (size_t)batch), flatScene, &oom);
 			if (rc && oom && perLaunch > 1 && n > 1)
 			{
 				perLaunch = (perLaunch + 1) / 2;
+				maxFit = perLaunch;  // (no stretched launches either)
 				continue;
 			}
 			if (rc) return rc;

@@ -197,8 +197,9 @@ def test_interleaved_tiles_reproduce_the_full_image(rt, pa, cornell, ocornell, p
 
 
 def test_many_frames_per_launch_equal_frame_by_frame(rt, pa, cornell, ocornell):
-    """pt_render_frames(n) puts up to PT_FRAMES_PER_LAUNCH (8) frames into one launch of the persistent kernel:
-    19 frames in one call (launches of 8 + 8 + 3) == 19 single-frame calls == the oracle, bit for bit; the
+    """pt_render_frames(n) puts several frames into one launch of the persistent kernel (PT_FRAMES_PER_LAUNCH: 8, flat scenes
+    like this one 16; a call's last launch takes up to twice that rather than leave a short one behind): 19 frames in one
+    call (one launch of 19) and 53 frames (16 + 16 + 21) == as many single-frame calls == the oracle, bit for bit; the
     max_frames cut-off may fall inside a launch."""
     W, H = 50, 21
     view, proj = pa.reference_camera(W, H)
@@ -216,6 +217,11 @@ def test_many_frames_per_launch_equal_frame_by_frame(rt, pa, cornell, ocornell):
     for _ in range(19):
         rt.raytrace(1)
     assert rt.stats().rays_total == rays and np.array_equal(bits(rt.readImage()), bits(want))
+    rt.resetFrame()
+    rt.resetStats()
+    rt.raytrace(53)
+    want53, rays53 = ocornell.render(view, proj, W, H, frames=53, spp_per_frame=2, max_depth=6, seed=5)
+    assert rt.frame == 52 and rt.stats().rays_total == rays53 and np.array_equal(bits(rt.readImage()), bits(want53))
     rt.setParams(spp_per_frame=2, max_depth=6, seed=5, max_frames=11)  # frames 0..10 render, the rest are no-ops
     rt.resetFrame()
     rt.raytrace(19)
