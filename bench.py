@@ -168,6 +168,14 @@ def kernel_source_hash():
 PROFILE_SUFFIX = {"cornell": "", "viking": "_viking", "teapot": "_teapot", "soup": "_soup"}
 
 
+def profile_suffix(a):
+    """profiles/valu_paths<suffix>.json / traffic_paths<suffix>.json of this workload; the soup has one pair per size
+    (configs[4]'s 100 M triangles: _soup; bench.py's quick default of 1 M: _soup_1000000)"""
+    if a.scene == "soup" and int(a.tris) != 100_000_000:
+        return f"_soup_{int(a.tris)}"
+    return PROFILE_SUFFIX[a.scene]
+
+
 def workload_key(a):
     """What a PMC summary must have been taken on for its per-ray constants to price this run (the number of frames does
     not enter: the constants are per ray)."""
@@ -431,7 +439,7 @@ def main():
         hbm_achieved = (rays_per_launch * bytes_per_ray + (0.0 if traversal_from_hbm else scene_bytes)) / sec / 1e9 if sec > 0 else 0.0
         # hardware-counter constants of this kernel on this workload, from the committed --pmc summaries (per RAY, so that
         # they compare with bytes_per_ray whatever the launch length)
-        sfx, wkey = PROFILE_SUFFIX[a.scene], workload_key(a)
+        sfx, wkey = profile_suffix(a), workload_key(a)
         tj = load_profile_json({"persistent": f"traffic_paths{sfx}.json", "fused": "traffic_bounce.json"}.get(a.pipeline, "none"), wkey)
         traffic_per_ray = tj.get("hbm_bytes_per_ray") if tj else None
         traffic = round(traffic_per_ray * rays_per_launch) if traffic_per_ray else None
@@ -541,10 +549,10 @@ def cpu_baseline_pixels(a, scene, view, proj, tmax, budget_s=8.0):
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     import oracle as O
     n_tris = scene.n_tris
-    if a.instances is None and n_tris > 5_000_000:
+    if a.instances is None and n_tris > 2_000_000:
         return {"value": None, "unit": "Mrays/s", "cores": O.max_threads(), "kind": "port",
-                "sample": f"not run: the oracle's single-threaded BVH2 build over {n_tris} triangles takes minutes; "
-                          "run --scene soup --tris 1e6 for the CPU rate on the same generator"}
+                "sample": f"not run: the oracle's single-threaded BVH2 build over {n_tris} triangles takes ~7 us per triangle "
+                          f"(~{7e-6 * n_tris / 60:.0f} min here); --scene soup --tris 1e6 times the CPU on the same generator"}
     t0 = time.perf_counter()
     osc = O.OracleScene(scene.vertices, scene.indices, scene.materials, scene.mat_indices, instances=a.instances,
                         texture=a.texture)
