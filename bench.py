@@ -448,6 +448,9 @@ def main():
                "traffic_bytes_per_ray": round(traffic_per_ray, 2) if traffic_per_ray else None,
                "bytes_per_ray": round(bytes_per_ray, 2),
                "traffic_over_algorithmic": round(traffic_per_ray / bytes_per_ray, 3) if traffic_per_ray else None,
+               # what the counters say left the L2 per second (FETCH_SIZE counts Infinity-Cache hits too: an upper bound on HBM)
+               "traffic_gbs": round(traffic_per_ray * rays_per_launch / sec / 1e9, 1) if (traffic_per_ray and sec > 0) else None,
+               "traffic_frac_of_hbm_peak": round(traffic_per_ray * rays_per_launch / sec / 1e9 / HBM_PEAK_GBS, 4) if (traffic_per_ray and sec > 0) else None,
                "kernel": kernel, "launch_ms": round(ext_ms, 4), "rays_per_launch": rays_per_launch,
                "p_alive": round(p_alive, 4), "p_hit": round(p_hit, 4),
                "traversal_bytes_counted": traversal_from_hbm, "scene_bytes": scene_bytes,
