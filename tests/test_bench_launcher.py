@@ -80,3 +80,54 @@ def test_self_launch_runs_ranks_and_relays_one_line(monkeypatch, tmp_path, capfd
 def test_lavapipe_probe_reports_what_it_looked_for():
     msg = bench.probe_lavapipe()
     assert msg.startswith(("unavailable:", "present")) and "ICD" in msg
+
+
+# ---------------------------------------------------------------- per-workload counter constants (round 3) ----
+def test_profile_constants_are_keyed_by_workload_and_kernel_sources(monkeypatch, tmp_path, capsys):
+    """bench.py prices a run with the committed PMC summary of ITS workload only: the file name carries the scene (and the
+    soup's size), the summary records the bench line's profile_workload and the hash of the kernel sources, and a mismatch
+    of either makes load_profile_json return None (the line then has no VALU roofline rather than a wrong one)."""
+    a = bench.parse(["--scene", "soup", "--tris", "1e6", "--builder", "lbvh"])
+    b = bench.parse(["--scene", "soup", "--tris", "1e8", "--builder", "lbvh"])
+    c = bench.parse([])
+    assert bench.profile_suffix(a) == "_soup_1000000" and bench.profile_suffix(b) == "_soup" and bench.profile_suffix(c) == ""
+    assert bench.profile_suffix(bench.parse(["--scene", "teapot"])) == "_teapot"
+    assert bench.workload_key(a) != bench.workload_key(b) and "tris1000000" in bench.workload_key(a)
+    assert bench.workload_key(c) == "cornell 1920x1080 spp16 depth8 ploc persistent"
+    assert bench.workload_key(bench.parse(["--steps", "3"])) == bench.workload_key(c)  # the frame count does not enter
+    monkeypatch.setattr(bench, "ROOT", str(tmp_path))
+    (tmp_path / "profiles").mkdir()
+    monkeypatch.setattr(bench, "kernel_source_hash", lambda: "abc")
+    good = {"kernel_sources_sha": "abc", "workload": bench.workload_key(c), "valu_wave_insts_per_ray": 12.3}
+    (tmp_path / "profiles" / "valu_paths.json").write_text(json.dumps(good))
+    assert bench.load_profile_json("valu_paths.json", bench.workload_key(c))["valu_wave_insts_per_ray"] == 12.3
+    assert bench.load_profile_json("valu_paths.json", bench.workload_key(a)) is None       # another workload
+    assert "not used" in capsys.readouterr().err
+    monkeypatch.setattr(bench, "kernel_source_hash", lambda: "other")
+    assert bench.load_profile_json("valu_paths.json", bench.workload_key(c)) is None       # other kernel sources
+    assert bench.load_profile_json("missing.json", bench.workload_key(c)) is None
+
+
+def test_committed_profiles_match_the_kernel_sources_in_the_tree():
+    """The summaries under profiles/ that bench.py loads were taken on THESE kernel sources (otherwise the round-end bench
+    line silently loses its roofline): regenerate with scripts/gpu_round_profile.sh / gpu_scene_profile.sh + collect_profile.sh."""
+    sha = bench.kernel_source_hash()
+    for name in ("valu_paths", "traffic_paths", "valu_paths_viking", "traffic_paths_viking", "valu_paths_teapot",
+                 "traffic_paths_teapot", "valu_paths_soup", "traffic_paths_soup", "valu_paths_soup_1000000",
+                 "traffic_paths_soup_1000000"):
+        d = json.load(open(os.path.join(ROOT, "profiles", name + ".json")))
+        assert d["kernel_sources_sha"] == sha, name
+        assert d.get("workload"), name
+
+
+def test_cpu_baseline_on_a_pixel_sample(monkeypatch):
+    """cpu_baseline_pixels (the scenes other than the Cornell box): the oracle on a seeded pixel sample, rays / second."""
+    sys.path.insert(0, ROOT)
+    import pathtracer_amd as pa
+    a = bench.parse(["--scene", "teapot", "--width", "64", "--height", "48", "--spp-per-frame", "2", "--depth", "3",
+                     "--cpu-sample-pixels", "50"])
+    sc, view, proj, tmax, _ = bench.build_scene(a, pa)
+    a.instances = a.instances[:9]  # nine teapots are enough here
+    out = bench.cpu_baseline_pixels(a, sc, view, proj, tmax, budget_s=0.05)
+    assert out["kind"] == "port" and out["unit"] == "Mrays/s" and out["value"] > 0 and out["cores"] >= 1
+    assert "random pixels of 64x48" in out["sample"] and "no top-level structure" in out["sample"]
