@@ -1002,7 +1002,10 @@ __global__ void __launch_bounds__(kBlock) k_write_tris(const uint32_t *leafPrim,
 // surface area; mutual nearest neighbours merge; the survivors are compacted in order; repeat until
 // one cluster is left.  BVH2 node ids: leaf for sorted position k = (n-1)+k, internal nodes are numbered
 // 0.. in creation order (deterministic: exclusive scan of the merge flags), the root is the last one.
-constexpr int kPlocRadius = 16;
+#ifndef PT_PLOC_RADIUS
+#define PT_PLOC_RADIUS 16
+#endif
+constexpr int kPlocRadius = PT_PLOC_RADIUS;
 
 __global__ void __launch_bounds__(kBlock) k_ploc_leaves(const float4 *triLo, const float4 *triHi,
                                                         const uint32_t *sortedPrim, int n, const int *bounds,
