@@ -673,6 +673,65 @@ int buildTopLevel(pt_ctx *c, int builder)
 	in.padExp = 14;  // the object-space hit test and the world-space box disagree by the rounding of two transforms
 	PtBuildOutput top;
 	if (e == hipSuccess) e = ptBuildBvh4(in, top, c->stream);
+	// Which builder makes the better tree over a set of instance boxes depends on the layout: on a regular grid the Morton
+	// order IS the right hierarchy and LBVH wins (teapot x 64 x 64: 10.1 against 9.1 Grays/s), on scattered or clustered
+	// instances PLOC does (+3...6 %, scripts/gpu_tlas_builder.py).  The top level is a few thousand boxes and a few
+	// milliseconds, so BOTH are built and the one with the smaller surface-area cost -- the sum of its wide nodes' box areas,
+	// i.e. the expected number of node visits of a random ray, up to a constant -- is kept.  PT_TLAS_BUILDER=lbvh|ploc forces one.
+	const char *forced = getenv("PT_TLAS_BUILDER");
+	if (e == hipSuccess && n > 4 && !forced)
+	{
+		auto cost = [&](const PtBuildOutput &t, double &out) -> hipError_t {
+			std::vector<PtNode4> h(t.nNodes);
+			hipError_t ce = hipMemcpy(h.data(), t.nodes, sizeof(PtNode4) * t.nNodes, hipMemcpyDeviceToHost);
+			out = 0.0;
+			for (const PtNode4 &nd : h)
+			{
+				const float scale[3] = { nd.scaleX, nd.scaleY, nd.scaleZ };
+				double lo[3] = { INFINITY, INFINITY, INFINITY }, hi[3] = { -INFINITY, -INFINITY, -INFINITY };
+				for (int ch = 0; ch < 4; ++ch)
+				{
+					if (nd.child[ch] == PT_EMPTY_CHILD) continue;
+					for (int a = 0; a < 3; ++a)
+					{
+						const double l = (double)nd.origin[a] + (double)((nd.qlo[a] >> (8 * ch)) & 0xFFu) * scale[a];
+						const double u = (double)nd.origin[a] + (double)((nd.qhi[a] >> (8 * ch)) & 0xFFu) * scale[a];
+						if (l < lo[a]) lo[a] = l;
+						if (u > hi[a]) hi[a] = u;
+					}
+				}
+				const double dx = hi[0] - lo[0], dy = hi[1] - lo[1], dz = hi[2] - lo[2];
+				if (dx >= 0.0 && dy >= 0.0 && dz >= 0.0) out += dx * dy + dy * dz + dz * dx;
+			}
+			return ce;
+		};
+		PtBuildInput in2 = in;
+		in2.builder = builder == PT_BUILDER_PLOC ? PT_BUILDER_LBVH : PT_BUILDER_PLOC;
+		PtBuildOutput other;
+		e = ptBuildBvh4(in2, other, c->stream);
+		double costTop = 0.0, costOther = 0.0;
+		if (e == hipSuccess) e = cost(top, costTop);
+		if (e == hipSuccess) e = cost(other, costOther);
+		PtBuildOutput &drop = (e == hipSuccess && costOther < costTop) ? top : other;
+		hipFree(drop.nodes);
+		hipFree(drop.tris);
+		hipFree(drop.codes);
+		hipFree(drop.order);
+		if (&drop == &top) top = other;
+	}
+	else if (e == hipSuccess && forced)
+	{
+		const int want = (forced[0] == 'l' || forced[0] == 'L') ? PT_BUILDER_LBVH : PT_BUILDER_PLOC;
+		if (want != builder)
+		{
+			hipFree(top.nodes);
+			hipFree(top.tris);
+			hipFree(top.codes);
+			hipFree(top.order);
+			in.builder = want;
+			e = ptBuildBvh4(in, top, c->stream);
+		}
+	}
 	hipFree(dLo);
 	hipFree(dHi);
 	if (e != hipSuccess) return fail(c, PT_EHIP, "pt_build_accel: top-level build failed: %s", hipGetErrorString(e));

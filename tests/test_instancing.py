@@ -142,6 +142,24 @@ def test_grid_of_rotated_meshes_bit_exact(rt, pa, O):
     assert rt.stats().rays_total == rays
     assert np.array_equal(bits(rt.readImage()), bits(want))
     assert (want[..., :3].sum(axis=2) > 0).mean() > 0.2
+    # The top-level tree is built with BOTH builders and the one with the smaller surface-area cost is kept (round 3);
+    # PT_TLAS_BUILDER forces one.  Whatever tree is traversed, the image and the ray count are the oracle's.
+    import os
+    nodes = {}
+    try:
+        for forced in ("lbvh", "ploc"):
+            os.environ["PT_TLAS_BUILDER"] = forced
+            rt.buildBlas(sc)
+            nodes[forced] = rt.stats().bvh_nodes
+            rt.resize(W, H)
+            rt.setCamera(view, proj)
+            rt.resetStats()
+            rt.raytrace(2)
+            assert rt.stats().rays_total == rays, forced
+            assert np.array_equal(bits(rt.readImage()), bits(want)), forced
+    finally:
+        os.environ.pop("PT_TLAS_BUILDER", None)
+    assert st.bvh_nodes in nodes.values()  # the unforced build kept one of the two
 
 
 @pytest.mark.gpu
