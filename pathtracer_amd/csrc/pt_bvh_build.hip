@@ -56,7 +56,7 @@ __device__ __forceinline__ float waveMax(float v)
 // id), written here where the vertices are gathered anyway in primitive order; k_write_tris then needs ONE gathered
 // record per triangle in leaf order instead of an index triple and three vertices.
 __global__ void __launch_bounds__(kBlock) k_tri_setup(const PtVertex *verts, const uint32_t *indices, uint32_t nTris,
-                                                      float4 *triLo, float4 *triHi, int *bounds, float4 *triPos)
+                                                      float4 *triLo, float4 *triHi, int *bounds, float4 *triPos, float *centroid)
 {
 	float cmin[3] = { FLT_MAX, FLT_MAX, FLT_MAX }, cmax[3] = { -FLT_MAX, -FLT_MAX, -FLT_MAX };
 	float amax = 0.0f;
@@ -80,12 +80,16 @@ __global__ void __launch_bounds__(kBlock) k_tri_setup(const PtVertex *verts, con
 		triPos[3 * (size_t)i + 0] = make_float4(q[0][0], q[0][1], q[0][2], q[1][0]);
 		triPos[3 * (size_t)i + 1] = make_float4(q[1][1], q[1][2], q[2][0], q[2][1]);
 		triPos[3 * (size_t)i + 2] = make_float4(q[2][2], 0.0f, 0.0f, 0.0f);
-		triLo[2 * (size_t)i] = make_float4(lo[0], lo[1], lo[2], 0.0f);
-		triHi[2 * (size_t)i] = make_float4(hi[0], hi[1], hi[2], 0.0f);
+		if (!centroid)  // (uniform)
+		{
+			triLo[2 * (size_t)i] = make_float4(lo[0], lo[1], lo[2], 0.0f);
+			triHi[2 * (size_t)i] = make_float4(hi[0], hi[1], hi[2], 0.0f);
+		}
 #pragma unroll
 		for (int k = 0; k < 3; ++k)
 		{
 			float c = (lo[k] + hi[k]) * 0.5f;
+			if (centroid) centroid[3 * (size_t)i + k] = c;
 			if (c < cmin[k]) cmin[k] = c;
 			if (c > cmax[k]) cmax[k] = c;
 			amax = fmaxf(amax, fmaxf(fabsf(lo[k]), fabsf(hi[k])));
@@ -150,13 +154,26 @@ __device__ __forceinline__ uint32_t expandBits10(uint32_t v)
 	return v;
 }
 
-__global__ void __launch_bounds__(kBlock) k_morton(const float4 *triLo, const float4 *triHi, uint32_t nTris,
-                                                   const int *bounds, uint32_t *codes, uint32_t *keys, uint32_t *vals)
+// centroid: the box centres as k_tri_setup formed them (12 bytes per triangle; the LBVH over triangles needs nothing else of
+// the primitive boxes -- k_refit takes them from the position records), else they are formed here from the boxes.
+__global__ void __launch_bounds__(kBlock) k_morton(const float4 *triLo, const float4 *triHi, const float *centroid, uint32_t nTris,
+                                                   const int *bounds, uint32_t *codes)
 {
 	uint32_t i = blockIdx.x * kBlock + threadIdx.x;
 	if (i >= nTris) return;
-	float4 lo = triLo[2 * (size_t)i], hi = triHi[2 * (size_t)i];
-	float c[3] = { (lo.x + hi.x) * 0.5f, (lo.y + hi.y) * 0.5f, (lo.z + hi.z) * 0.5f };
+	float c[3];
+	if (centroid)  // (uniform)
+	{
+#pragma unroll
+		for (int k = 0; k < 3; ++k) c[k] = centroid[3 * (size_t)i + k];
+	}
+	else
+	{
+		float4 lo = triLo[2 * (size_t)i], hi = triHi[2 * (size_t)i];
+		c[0] = (lo.x + hi.x) * 0.5f;
+		c[1] = (lo.y + hi.y) * 0.5f;
+		c[2] = (lo.z + hi.z) * 0.5f;
+	}
 	uint32_t q[3];
 #pragma unroll
 	for (int k = 0; k < 3; ++k)
@@ -170,9 +187,7 @@ __global__ void __launch_bounds__(kBlock) k_morton(const float4 *triLo, const fl
 		q[k] = (uint32_t)s;
 	}
 	uint32_t code = (expandBits10(q[0]) << 2) | (expandBits10(q[1]) << 1) | expandBits10(q[2]);
-	codes[i] = code;
-	keys[i] = code;
-	vals[i] = i;
+	codes[i] = code;  // the first sort pass reads the codes where they lie and numbers the primitives itself
 }
 
 // ------------------------------------------------------------------- radix sort ----
@@ -345,7 +360,7 @@ __global__ void __launch_bounds__(kBlock) k_radix_scatter(const uint32_t *keysIn
 		size_t i = waveBase + r * PT_WAVE + lane;
 		bool valid = i < n;
 		key[r] = valid ? keysIn[i] : 0xFFFFFFFFu;
-		val[r] = valid ? valsIn[i] : 0u;
+		val[r] = valid ? (valsIn ? valsIn[i] : (uint32_t)i) : 0u;  // valsIn == nullptr: the first pass, value = position
 		uint32_t digit = (key[r] >> shift) & kMask;
 		// lanes of this round holding the same digit (and the same validity)
 		unsigned long long peers = __ballot(valid);
@@ -1162,10 +1177,12 @@ hipError_t ptBuildBvh4(const PtBuildInput &in, PtBuildOutput &out, hipStream_t s
 	};
 	// primitive boxes interleaved (lo, hi) in ONE array: the gathers through the sorted order touch one 32-byte record per
 	// primitive instead of two 16-byte ones in different arrays; the kernels see it as two pointers with a stride of 2
-	const size_t oTriLo = reserve(2 * sizeof(float4) * n), oBounds = reserve(64);
+	// (the LBVH over triangles keeps only the box centres: 12 bytes per triangle instead of 32 to write and to read back)
+	const bool needPrimBoxes = ploc || boxMode;
+	const size_t oTriLo = reserve(needPrimBoxes ? 2 * sizeof(float4) * (size_t)n : 0), oBounds = reserve(64);
+	const size_t oCentroid = reserve(needPrimBoxes ? 0 : 3 * sizeof(float) * (size_t)n);
 	const size_t oTriPos = reserve(boxMode ? 0 : 3 * sizeof(float4) * (size_t)n);
-	const size_t oKeysA = reserve(4 * (size_t)n), oKeysB = reserve(4 * (size_t)n), oValsA = reserve(4 * (size_t)n),
-	             oValsB = reserve(4 * (size_t)n);
+	const size_t oKeysA = reserve(4 * (size_t)n), oKeysB = reserve(4 * (size_t)n), oValsX = reserve(4 * (size_t)n);
 	const size_t oHist = reserve(4 * histLen), oScan = reserve(4 * scanScratchLen(histLen));
 	// LBVH: one 16-byte topology record per internal node + the leaves' parents; PLOC: children + subtree leaf counts
 	const size_t oTopo = reserve(ploc ? 0 : sizeof(int4) * n), oLeafParent = reserve(ploc ? 0 : sizeof(int) * n);
@@ -1184,8 +1201,9 @@ hipError_t ptBuildBvh4(const PtBuildInput &in, PtBuildOutput &out, hipStream_t s
 #define AT(T, off) reinterpret_cast<T *>(arena + (off))
 	float4 *triLo = AT(float4, oTriLo), *triHi = triLo + 1, *triPos = AT(float4, oTriPos);
 	int *bounds = AT(int, oBounds);
-	uint32_t *keysA = AT(uint32_t, oKeysA), *keysB = AT(uint32_t, oKeysB), *valsA = AT(uint32_t, oValsA),
-	         *valsB = AT(uint32_t, oValsB), *hist = AT(uint32_t, oHist), *scanScratch = AT(uint32_t, oScan);
+	float *centroid = needPrimBoxes ? nullptr : AT(float, oCentroid);
+	uint32_t *keysA = AT(uint32_t, oKeysA), *keysB = AT(uint32_t, oKeysB), *valsX = AT(uint32_t, oValsX),
+	         *hist = AT(uint32_t, oHist), *scanScratch = AT(uint32_t, oScan);
 	int4 *topo = AT(int4, oTopo);
 	int *leafParent = AT(int, oLeafParent);
 	int2 *children = AT(int2, oChildren);
@@ -1216,23 +1234,24 @@ hipError_t ptBuildBvh4(const PtBuildInput &in, PtBuildOutput &out, hipStream_t s
 		if (boxMode) k_box_setup<<<gridTris, kBlock, 0, stream>>>(in.boxLo, in.boxHi, n, triLo, triHi, bounds);
 		else
 			k_tri_setup<<<gridTris < 2048 ? gridTris : 2048, kBlock, 0, stream>>>(in.vertices, in.indices, n, triLo, triHi,
-			                                                                       bounds, triPos);
-		k_morton<<<gridTris, kBlock, 0, stream>>>(triLo, triHi, n, bounds, codes, keysA, valsA);
-		uint32_t *kin = keysA, *kout = keysB, *vin = valsA, *vout = valsB;
-		for (int shift = 0; shift < kSortBits; shift += kRadixBits)
+			                                                                       bounds, triPos, centroid);
+		k_morton<<<gridTris, kBlock, 0, stream>>>(triLo, triHi, centroid, n, bounds, codes);
+		// The first pass reads the codes where k_morton left them (the `codes` output, never written again) and takes a key's
+		// position as its value; the value buffers alternate so that the LAST pass scatters into the `order` output -- no copy
+		// of the keys in, none of the sorted order out (0.4 GB each way per copy at 100 M primitives).
+		constexpr int kPasses = kSortBits / kRadixBits;
+		const uint32_t *kin = codes, *vin = nullptr;
+		for (int pass = 0; pass < kPasses; ++pass)
 		{
+			const int shift = pass * kRadixBits;
+			uint32_t *kout = (pass & 1) ? keysB : keysA, *vout = ((kPasses - 1 - pass) & 1) ? valsX : order;
 			k_radix_hist<<<nSortBlocks, kBlock, 0, stream>>>(kin, n, shift, hist, nSortBlocks);
 			scanExclusive<uint32_t>(hist, histLen, scanScratch, nullptr, stream);
 			k_radix_scatter<<<nSortBlocks, kBlock, 0, stream>>>(kin, vin, kout, vout, n, shift, hist, nSortBlocks);
-			uint32_t *t = kin;
 			kin = kout;
-			kout = t;
-			t = vin;
 			vin = vout;
-			vout = t;
 		}
-		// (kin, vin) hold the sorted data whatever the number of passes
-		err = hipMemcpyAsync(order, vin, 4 * (size_t)n, hipMemcpyDeviceToDevice, stream);
+		// (kin, vin) hold the sorted keys and primitives; vin == order
 		int rootNode = 0;  // LBVH: internal node 0 (or the only leaf, index 0, when n == 1)
 		if (err == hipSuccess && !ploc)
 		{
