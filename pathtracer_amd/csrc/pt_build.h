@@ -22,6 +22,9 @@ struct PtBuildInput
 	// traversal), 1 = the identity plane only (the traversal permutes with selects): a third of the bytes to write and keep,
 	// for scenes whose traversal waits for HBM anyway
 	int triPlanes = 3;
+	// recorded on the stream behind the build's last kernel when given: the tree is complete there; what follows in
+	// ptBuildBvh4 (two small read-backs, the release of the scratch arena) is host work with an idle device
+	hipEvent_t doneEvent = nullptr;
 };
 
 struct PtBuildOutput

@@ -447,7 +447,7 @@ template <typename KeyAt> __device__ __forceinline__ int lbvhDelta(const KeyAt &
 // The searches of a node read keys near its own position -- a node's range is short for all but the top of the tree -- so the
 // block keeps the keys of its 256 positions and of 256 either side in LDS (3 KB) and only the long ranges go to memory: the
 // kernel was a chain of dependent loads (2.5 ms at 100 M keys, 1.3 TB/s of traffic).
-__global__ void __launch_bounds__(kBlock) k_lbvh_topology(const uint32_t *keys, int n, int4 *topo, int *leafParent)
+__global__ void __launch_bounds__(kBlock) k_lbvh_topology(const uint32_t *keys, int n, int4 *topo, int *leafParent, unsigned int *arrive)
 {
 	__shared__ uint32_t sKeys[3 * kBlock];
 	const int winFirst = (int)(blockIdx.x * kBlock) - kBlock;  // position of sKeys[0]
@@ -459,6 +459,7 @@ __global__ void __launch_bounds__(kBlock) k_lbvh_topology(const uint32_t *keys, 
 	__syncthreads();
 	int i = blockIdx.x * kBlock + threadIdx.x;
 	if (i >= n - 1) return;
+	arrive[i] = 0u;  // the refit's arrival counter of this node (instead of a 4n-byte fill of its own)
 	auto at = [&](int j) -> uint32_t {
 		const int k = j - winFirst;
 		return (k >= 0 && k < 3 * kBlock) ? sKeys[k] : keys[j];
@@ -1220,11 +1221,7 @@ hipError_t ptBuildBvh4(const PtBuildInput &in, PtBuildOutput &out, hipStream_t s
 	PtNode4 *nodes = nullptr;
 	PtTri48 *tris = nullptr;
 	uint32_t *codes = nullptr, *order = nullptr;
-	TRY(hipMalloc(&nodes, sizeof(PtNode4) * (size_t)n));  // a wide node has >= 2 children unless it is the root
 	const int planes = in.triPlanes == 1 ? 1 : 3;
-	if (!boxMode) TRY(hipMalloc(&tris, (size_t)planes * sizeof(PtTri48) * (size_t)n));  // three axis-rotated planes, or the identity
-	TRY(hipMalloc(&codes, 4 * (size_t)n));
-	TRY(hipMalloc(&order, 4 * (size_t)n));
 
 	uint32_t depth = 0, nodeCount = 0;
 	if (err == hipSuccess)
@@ -1235,6 +1232,17 @@ hipError_t ptBuildBvh4(const PtBuildInput &in, PtBuildOutput &out, hipStream_t s
 		else
 			k_tri_setup<<<gridTris < 2048 ? gridTris : 2048, kBlock, 0, stream>>>(in.vertices, in.indices, n, triLo, triHi,
 			                                                                       bounds, triPos, centroid);
+		// The four outputs are allocated while the device runs the set-up kernel, which needs none of them: a hipMalloc is
+		// ~0.3 ms of host time whatever its size (scripts/ubench/malloc_time.hip), and four of them in front of the first
+		// launch were 1.2 ms of every build in which the device did nothing.
+		TRY(hipMalloc(&codes, 4 * (size_t)n));
+		TRY(hipMalloc(&order, 4 * (size_t)n));
+		TRY(hipMalloc(&nodes, sizeof(PtNode4) * (size_t)n));  // a wide node has >= 2 children unless it is the root
+		if (!boxMode) TRY(hipMalloc(&tris, (size_t)planes * sizeof(PtTri48) * (size_t)n));  // three axis-rotated planes, or the identity
+	}
+	if (err == hipSuccess)
+	{
+		const uint32_t gridTris = divUp(n, kBlock);
 		k_morton<<<gridTris, kBlock, 0, stream>>>(triLo, triHi, centroid, n, bounds, codes);
 		// The first pass reads the codes where k_morton left them (the `codes` output, never written again) and takes a key's
 		// position as its value; the value buffers alternate so that the LAST pass scatters into the `order` output -- no copy
@@ -1255,8 +1263,7 @@ hipError_t ptBuildBvh4(const PtBuildInput &in, PtBuildOutput &out, hipStream_t s
 		int rootNode = 0;  // LBVH: internal node 0 (or the only leaf, index 0, when n == 1)
 		if (err == hipSuccess && !ploc)
 		{
-			err = hipMemsetAsync(arrive, 0, sizeof(unsigned int) * n, stream);
-			if (n > 1) k_lbvh_topology<<<divUp(n - 1, kBlock), kBlock, 0, stream>>>(kin, (int)n, topo, leafParent);
+			if (n > 1) k_lbvh_topology<<<divUp(n - 1, kBlock), kBlock, 0, stream>>>(kin, (int)n, topo, leafParent, arrive);
 			else TRY(hipMemsetAsync(leafParent, 0xFF, sizeof(int), stream));  // single leaf: parent = -1
 			// leaf boxes, the bottom-up union and (triangles) the leaf-ordered triangle array: the LBVH's leaf order is the
 			// sorted order, so the thread that gathers a primitive's positions for its box writes its three records too
@@ -1332,6 +1339,7 @@ hipError_t ptBuildBvh4(const PtBuildInput &in, PtBuildOutput &out, hipStream_t s
 		}
 		if (err == hipSuccess && leafPrim) k_write_tris<<<gridTris, kBlock, 0, stream>>>(leafPrim, n, triPos, tris, planes);
 		TRY(hipGetLastError());
+		if (in.doneEvent) TRY(hipEventRecord(in.doneEvent, stream));
 	}
 	if (err == hipSuccess)
 	{
