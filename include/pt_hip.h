@@ -71,7 +71,7 @@ typedef struct PtStats
 	uint32_t bvh_depth;         /* wide-node levels */
 	uint32_t bvh_tris;
 	uint32_t reserved;
-	double build_ms;            /* last pt_build_accel, device time */
+	double build_ms;            /* last pt_build_accel: device time from the call's first launch (scratch allocation included) to the tree's last kernel; compaction, quad leaves and entry node are outside */
 	/* Traversal work counters, only collected under PT_PROFILE_TRAVERSAL (instrumented kernel): */
 	uint64_t trav_nodes;        /* wide nodes fetched (the entry node of the persistent pipeline counts as one per ray) */
 	uint64_t trav_tris;         /* ray/triangle tests */
