@@ -56,7 +56,7 @@ def test_self_launch_runs_ranks_and_relays_one_line(monkeypatch, tmp_path, capfd
     script = tmp_path / "rank.py"
     script.write_text("import os, json\n"
                       "r, w = int(os.environ['RANK']), int(os.environ['WORLD_SIZE'])\n"
-                      "print('noise from rank', r, flush=True)\n"
+                      "print('noise from rank %d' % r, flush=True)\n"
                       "if r == 0: print(json.dumps({'metric': 'Mrays/s', 'n_gpus': w}), flush=True)\n")
     real = bench.launch_command
 
