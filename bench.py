@@ -79,6 +79,10 @@ def parse(argv=None):
                          "larger sample is sized from it to ~8 s of CPU work)")
     ap.add_argument("--force-dist", action="store_true",
                     help="go through torch.distributed/RCCL even for one rank (rehearses the N>1 path on one GPU)")
+    ap.add_argument("--dist-backend", choices=["nccl", "gloo"], default="nccl",
+                    help="nccl = RCCL over xGMI, one GPU per rank (the measured path).  gloo = REHEARSAL of the N>1 code path "
+                         "on a box with fewer GPUs than ranks: rank r renders on GPU r %% device_count, the image reduce goes "
+                         "through host memory -- the line says so and its value is not a scaling number")
     return ap.parse_args(argv)
 
 
@@ -267,14 +271,20 @@ def main():
     dist = None
     torch = None
     rccl = None
+    device = local_rank  # GPU of this rank
     if n_gpus > 1 or a.force_dist:
         import torch
         import torch.distributed as dist
         if world != n_gpus and not a.force_dist:
             raise SystemExit(f"--gpus {n_gpus} but WORLD_SIZE={world}")
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
-        world = dist.get_world_size()  # as RCCL sees it
+        if a.dist_backend == "gloo":
+            device = local_rank % max(1, torch.cuda.device_count())  # rehearsal: ranks may share a GPU
+            torch.cuda.set_device(device)
+            dist.init_process_group("gloo")
+        else:
+            torch.cuda.set_device(local_rank)
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        world = dist.get_world_size()  # as the backend sees it
         try:
             rccl = ".".join(str(x) for x in torch.cuda.nccl.version())
         except Exception:
@@ -287,7 +297,7 @@ def main():
 
     W, H, S, D = a.width, a.height, a.spp_per_frame, a.depth
     scene, view, proj, tmax, scene_name = build_scene(a, pa)
-    rt = pa.HipRaytracing(local_rank)
+    rt = pa.HipRaytracing(device)
     if a.instances is not None:
         rt.setInstances(a.instances)
     rt.buildBlas(scene, pa.api.PT_ACCEL_BVH4_PLOC if a.builder == "ploc" else pa.api.PT_ACCEL_BVH4)
@@ -326,7 +336,7 @@ def main():
 
     img_t = None
     if dist is not None:
-        img_t = torch.as_tensor(_DevArray(rt.imageDevicePtr(), (H, W, 4)), device=f"cuda:{local_rank}")
+        img_t = torch.as_tensor(_DevArray(rt.imageDevicePtr(), (H, W, 4)), device=f"cuda:{device}")
 
     def run(frames):
         rt.raytrace(frames)
@@ -371,6 +381,11 @@ def main():
     rt.resetFrame()
     rt.resetStats()
     rt.setProfiling(PT_PROFILE_KERNELS)
+    if dist is not None and tiles:
+        # the warm-up's reduce left the other ranks' tiles in rank 0's image; a rank's first frame overwrites its OWN tile only,
+        # and "zero outside the tile" is what makes reduce(sum) a gather (pt_resize zeroes the image, nothing after it does)
+        img_t.zero_()
+        torch.cuda.synchronize()
 
     # ---- timed region: exactly K steps ----
     barrier()
@@ -382,7 +397,7 @@ def main():
     st = rt.stats()
     rays_local = float(st.rays_total)
     if dist is not None:
-        v = torch.tensor([dt, rays_local], dtype=torch.float64, device=f"cuda:{local_rank}")
+        v = torch.tensor([dt, rays_local], dtype=torch.float64, device="cpu" if a.dist_backend == "gloo" else f"cuda:{device}")
         mx = v.clone()
         dist.all_reduce(mx, op=dist.ReduceOp.MAX)
         sm = v.clone()
@@ -512,6 +527,9 @@ def main():
             "profile_workload": workload_key(a), "bench_args": " ".join(sys.argv[1:]),
             "bvh": {"nodes": st.bvh_nodes, "depth": st.bvh_depth, "tris": st.bvh_tris, "build_ms": round(st.build_ms, 3)},
             "distributed": ({"backend": "nccl (RCCL)", "rccl_version": rccl, "world_size": world,
+                             "launcher": "torch.distributed.run"} if (dist is not None and a.dist_backend == "nccl") else
+                            {"backend": "gloo (REHEARSAL: ranks share GPUs, host-memory reduce; not a scaling measurement)",
+                             "world_size": world, "gpus_visible": torch.cuda.device_count(),
                              "launcher": "torch.distributed.run"} if dist is not None else None),
             "reference_lavapipe": probe_lavapipe(),
         }

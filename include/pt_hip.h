@@ -162,9 +162,17 @@ int pt_upload_models(pt_ctx *ctx, const PtModelDesc *models, uint32_t n_models);
  * shaders: it ships textures/viking_room.png and carries Vertex::texCoord (main.cpp:1166-1176, V flipped) through to
  * raytrace.rchit but never samples it.  Defined here: hitValue (raytrace.rchit:54) = material diffuse x texel, texel =
  * bilinear, repeat-addressed lookup at the barycentrically interpolated texCoord in the sRGB-decoded image
- * (pt_srgb8_to_linear), row 0 = v 0.  One map per scene (the reference has one Model); rgba8 = NULL, w = h = 0
- * removes it.  May be called at any time before a frame; pt_upload_scene keeps it. */
+ * (pt_srgb8_to_linear), row 0 = v 0.  This map covers every primitive of the scene (the reference has one Model;
+ * pt_set_model_texture: one per Model); rgba8 = NULL, w = h = 0 removes it.  May be called at any time before a frame; pt_upload_scene keeps it. */
 int pt_set_texture(pt_ctx *ctx, const uint8_t *rgba8, uint32_t width, uint32_t height);
+
+/* One diffuse map per Model (raytrace.rchit:27: every per-Model buffer is reached through
+ * model.m[gl_InstanceCustomIndexEXT]; main.cpp:1192-1251 fills in one Model).  `model` indexes the array given to
+ * pt_upload_models (0 after pt_upload_scene); a hit on a primitive of that Model multiplies the material's diffuse colour
+ * with this map as pt_set_texture defines, a Model without a map keeps the plain colour.  rgba8 = NULL, w = h = 0 removes
+ * the Model's map.  Per-Model maps and the scene-wide map replace each other (the call that comes last wins); a new
+ * pt_upload_scene / pt_upload_models drops the per-Model maps (their primitive ranges are the old scene's). */
+int pt_set_model_texture(pt_ctx *ctx, uint32_t model, const uint8_t *rgba8, uint32_t width, uint32_t height);
 
 #define PT_ACCEL_BVH4 0         /* LBVH (Morton + LDS radix sort) collapsed to a quantised BVH4 */
 #define PT_ACCEL_BRUTE_FORCE 1  /* no hierarchy: every ray tests every triangle (parity/debug mode) */

@@ -17,7 +17,12 @@ class Scene(C.Structure):
     _fields_ = [("verts", C.c_void_p), ("nVerts", C.c_uint32), ("indices", C.c_void_p), ("nIdx", C.c_uint32),
                 ("materials", C.c_void_p), ("nMat", C.c_uint32), ("matIdx", C.c_void_p),
                 ("instances", C.c_void_p), ("nInst", C.c_uint32),
-                ("texture", C.c_void_p), ("texW", C.c_uint32), ("texH", C.c_uint32), ("instRange", C.c_void_p)]
+                ("texture", C.c_void_p), ("texW", C.c_uint32), ("texH", C.c_uint32), ("instRange", C.c_void_p),
+                ("texSlots", C.c_void_p), ("nTexSlots", C.c_uint32)]
+
+
+class TexSlot(C.Structure):
+    _fields_ = [("texels", C.c_void_p), ("w", C.c_uint32), ("h", C.c_uint32), ("primEnd", C.c_uint32), ("pad", C.c_uint32)]
 
 
 class Params(C.Structure):
@@ -192,10 +197,15 @@ class OracleScene:
             t0 += count[-1]
         ci = np.asarray(custom_index, np.uint32).reshape(-1)
         rng = np.stack([np.asarray(first, np.uint32)[ci], np.asarray(count, np.uint32)[ci]], axis=1)
+        if "model_textures" in kw:  # one diffuse map (or None) per Model -> (first primitive behind the Model, map)
+            mt = kw.pop("model_textures")
+            assert len(mt) == len(models)
+            kw["texture_slots"] = [(first[m] + count[m], mt[m]) for m in range(len(models))]
         return cls(np.concatenate(vs), np.concatenate(ids), np.concatenate(ms), np.concatenate(mis), instances=instances,
                    inst_range=rng, **kw)
 
-    def __init__(self, vertices, indices, materials, mat_indices, use_bvh=None, instances=None, texture=None, inst_range=None):
+    def __init__(self, vertices, indices, materials, mat_indices, use_bvh=None, instances=None, texture=None, inst_range=None,
+                 texture_slots=None):
         self.vertices = np.ascontiguousarray(vertices, dtype=np.float32).reshape(-1, 11)
         self.indices = np.ascontiguousarray(indices, dtype=np.uint32).reshape(-1)
         self.materials = np.ascontiguousarray(materials, dtype=np.float32).reshape(-1, 6)
@@ -227,6 +237,24 @@ class OracleScene:
             self.texture = np.ascontiguousarray(srgb8_to_linear_lut()[t])
             self.texture[..., 3] = t[..., 3].astype(np.float32) / np.float32(255.0)
             self.c.texture, self.c.texW, self.c.texH = _p(self.texture).value, t.shape[1], t.shape[0]
+        # texture_slots: [(prim_end, (H, W, 4) uint8 map or None), ...] in primitive order -- one diffuse map per Model
+        self.texture_slots = None
+        if texture_slots is not None:
+            assert texture is None
+            self._slot_texels = []
+            self.texture_slots = (TexSlot * len(texture_slots))()
+            for i, (prim_end, tex) in enumerate(texture_slots):
+                self.texture_slots[i].primEnd = int(prim_end)
+                if tex is not None:
+                    t = np.ascontiguousarray(tex, dtype=np.uint8)
+                    assert t.ndim == 3 and t.shape[2] == 4
+                    lin = np.ascontiguousarray(srgb8_to_linear_lut()[t])
+                    lin[..., 3] = t[..., 3].astype(np.float32) / np.float32(255.0)
+                    self._slot_texels.append(lin)
+                    self.texture_slots[i].texels = _p(lin).value
+                    self.texture_slots[i].w, self.texture_slots[i].h = t.shape[1], t.shape[0]
+            self.c.texSlots = C.cast(self.texture_slots, C.c_void_p).value
+            self.c.nTexSlots = len(texture_slots)
         if use_bvh is None:
             use_bvh = self.indices.size // 3 > 64
         self.bvh = lib().pto_bvh_build(C.byref(self.c)) if use_bvh else None

@@ -292,7 +292,18 @@ typedef struct
 	 * indices rebased by the caller), and instance ii contains only the primitives [instRange[2*ii], + instRange[2*ii+1]).
 	 * NULL: every instance shows the whole scene (one Model). */
 	const uint32_t *instRange;
+	/* One diffuse map per Model (the product's pt_set_model_texture): nTexSlots records in primitive order, slot m covers
+	 * the primitives below its primEnd that no earlier slot covers; texels NULL = that Model has no map.  NULL: the
+	 * scene-wide map above (or none). */
+	const struct PtoTexSlot *texSlots;
+	uint32_t nTexSlots;
 } PtoScene;
+
+typedef struct PtoTexSlot
+{
+	const float *texels;
+	uint32_t w, h, primEnd, pad;
+} PtoTexSlot;
 
 /* Repeat addressing, bilinear filter; every step in fp32 in exactly this order (this build's definition of the
  * lookup; the device's pt_sample_texture is the same expression tree). */
@@ -694,10 +705,20 @@ static inline int closest_hit(const PtoScene *sc, const PtoHit *h, uint32_t inst
 	o[0] = P[0]; o[1] = P[1]; o[2] = P[2];
 	emission[0] = mat[3]; emission[1] = mat[4]; emission[2] = mat[5];
 	hitValue[0] = mat[0]; hitValue[1] = mat[1]; hitValue[2] = mat[2];
-	if (sc->texture)
+	const float *tex = sc->texture;
+	uint32_t tw = sc->texW, th = sc->texH;
+	if (sc->texSlots)
+	{
+		uint32_t m = 0;
+		while (m + 1u < sc->nTexSlots && h->prim >= sc->texSlots[m].primEnd) ++m;
+		tex = sc->texSlots[m].texels;
+		tw = sc->texSlots[m].w;
+		th = sc->texSlots[m].h;
+	}
+	if (tex)
 	{
 		float tu = (v0[9] * bx + v1[9] * by) + v2[9] * bz, tv = (v0[10] * bx + v1[10] * by) + v2[10] * bz, tx[3];
-		pto_sample_texture(sc->texture, sc->texW, sc->texH, tu, tv, tx);
+		pto_sample_texture(tex, tw, th, tu, tv, tx);
 		for (int k = 0; k < 3; ++k) hitValue[k] = hitValue[k] * tx[k];
 	}
 	return !((mat[3] + mat[4]) + mat[5] > 0.0f);

@@ -108,6 +108,7 @@ SYMBOLS = {
     "pt_save_checkpoint": (_i, [_vp, C.c_char_p]),
     "pt_load_checkpoint": (_i, [_vp, C.c_char_p]),
     "pt_set_texture": (_i, [_vp, _vp, _u32, _u32]),
+    "pt_set_model_texture": (_i, [_vp, _u32, _vp, _u32, _u32]),
     "pt_load_png": (_i, [C.c_char_p, C.POINTER(_vp), C.POINTER(_u32), C.POINTER(_u32)]),
     "pt_free": (None, [_vp]),
     "pt_srgb8_to_linear": (None, [_vp, _u32, _vp]),

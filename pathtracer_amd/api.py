@@ -277,6 +277,15 @@ class HipRaytracing:
         assert t.ndim == 3 and t.shape[2] == 4
         self._check(self._L.pt_set_texture(self._ctx, _p(t), t.shape[1], t.shape[0]))
 
+    def setModelTexture(self, model: int, rgba8=None):
+        """Diffuse map of ONE Model of uploadModels (pt_set_model_texture), or None to remove it; replaces a scene-wide map."""
+        if rgba8 is None:
+            self._check(self._L.pt_set_model_texture(self._ctx, int(model), None, 0, 0))
+            return
+        t = np.ascontiguousarray(rgba8, dtype=np.uint8)
+        assert t.ndim == 3 and t.shape[2] == 4
+        self._check(self._L.pt_set_model_texture(self._ctx, int(model), _p(t), t.shape[1], t.shape[0]))
+
     def setTextureFromScene(self, scene: "Scene"):
         """The first map_Kd image the scene's MTL file names and that exists (what pt_render does without -tex); returns
         its path, or None (texture left as it was) when there is none.  One texture slot: pt_set_texture."""

@@ -71,6 +71,15 @@ struct pt_ctx
 	bool haveScene = false, haveAccel = false, brute = false;
 	float4 *dTexture = nullptr;  // optional diffuse map (pt_set_texture), linear RGBA
 	uint32_t texW = 0, texH = 0;
+	// one map per Model (pt_set_model_texture): texels of model m (nullptr: none) and the device table the shading searches
+	struct ModelTex
+	{
+		float4 *texels = nullptr;
+		uint32_t w = 0, h = 0;
+	};
+	std::vector<ModelTex> modelTex;
+	PtTexSlot *dTexSlots = nullptr;
+	uint32_t nTexSlots = 0;
 	PtBuildOutput accel;
 	PtQuadOutput quadAccel;  // quad leaves + the node array that refers to them (persistent pipeline only)
 	uint4 *dEntry = nullptr;  // entry node of the persistent pipeline (flattened tree top, pt_wave_traverse.h) or nullptr
@@ -185,8 +194,18 @@ void freeAccel(pt_ctx *c)
 	c->haveAccel = false;
 }
 
+void freeModelTextures(pt_ctx *c)
+{
+	for (pt_ctx::ModelTex &t : c->modelTex) hipFree(t.texels);
+	c->modelTex.clear();
+	hipFree(c->dTexSlots);
+	c->dTexSlots = nullptr;
+	c->nTexSlots = 0;
+}
+
 void freeScene(pt_ctx *c)
 {
+	freeModelTextures(c);  // (their slots follow the Models' primitive ranges; the scene-wide map stays)
 	hipFree(c->dVerts);
 	hipFree(c->dIndices);
 	hipFree(c->dMats);
@@ -239,6 +258,17 @@ PtSceneDev sceneDev(const pt_ctx *c)
 	s.texture = c->dTexture;
 	s.texW = c->texW;
 	s.texH = c->texH;
+	s.texSlots = c->dTexSlots;
+	s.nTexSlots = c->nTexSlots;
+	if (c->dTexSlots)  // per-Model maps: any of them marks the scene as one that samples maps
+		for (const pt_ctx::ModelTex &t : c->modelTex)
+			if (t.texels)
+			{
+				s.texture = t.texels;
+				s.texW = t.w;
+				s.texH = t.h;
+				break;
+			}
 	s.quads = nullptr;  // only the persistent pipeline traverses the quad version of the tree (renderPersistent)
 	s.nQuads = 0;
 	return s;
@@ -579,6 +609,29 @@ catch (const std::bad_alloc &)
 	return fail(c, PT_ENOMEM, "pt_upload_models: out of host memory");
 }
 
+namespace
+{
+// sRGB8 image -> linear float4 texels on the device (alpha is not a colour; the shading does not use it)
+int uploadTexels(pt_ctx *c, const char *who, const uint8_t *rgba8, uint32_t w, uint32_t h, float4 **out)
+{
+	const size_t n = (size_t)w * h;
+	std::vector<float> lin(4 * n);
+	pt_srgb8_to_linear(rgba8, (uint32_t)(4 * n), lin.data());
+	for (size_t i = 0; i < n; ++i) lin[4 * i + 3] = (float)rgba8[4 * i + 3] / 255.0f;
+	float4 *d = nullptr;
+	PT_HIP(c, hipMalloc(&d, sizeof(float4) * n));
+	hipError_t e = hipMemcpy(d, lin.data(), sizeof(float4) * n, hipMemcpyHostToDevice);
+	if (e != hipSuccess)
+	{
+		hipFree(d);  // never leave a map without an extent behind: the sampler divides by it
+		return fail(c, PT_EHIP, "%s: upload failed: %s", who, hipGetErrorString(e));
+	}
+	*out = d;
+	return PT_OK;
+}
+
+}  // namespace
+
 extern "C" int pt_set_texture(pt_ctx *c, const uint8_t *rgba8, uint32_t w, uint32_t h) try
 {
 	if (!c) return fail(nullptr, PT_EINVAL, "null context");
@@ -589,19 +642,10 @@ extern "C" int pt_set_texture(pt_ctx *c, const uint8_t *rgba8, uint32_t w, uint3
 	hipFree(c->dTexture);
 	c->dTexture = nullptr;
 	c->texW = c->texH = 0;
+	freeModelTextures(c);  // the scene-wide map replaces per-Model ones
 	if (!rgba8) return PT_OK;
-	const size_t n = (size_t)w * h;
-	std::vector<float> lin(4 * n);
-	pt_srgb8_to_linear(rgba8, (uint32_t)(4 * n), lin.data());
-	for (size_t i = 0; i < n; ++i) lin[4 * i + 3] = (float)rgba8[4 * i + 3] / 255.0f;  // alpha is not a colour (unused by the shading)
-	PT_HIP(c, hipMalloc(&c->dTexture, sizeof(float4) * n));
-	hipError_t e = hipMemcpy(c->dTexture, lin.data(), sizeof(float4) * n, hipMemcpyHostToDevice);
-	if (e != hipSuccess)
-	{
-		hipFree(c->dTexture);  // never leave a map without an extent behind: the sampler divides by it
-		c->dTexture = nullptr;
-		return fail(c, PT_EHIP, "pt_set_texture: upload failed: %s", hipGetErrorString(e));
-	}
+	int rc = uploadTexels(c, "pt_set_texture", rgba8, w, h, &c->dTexture);
+	if (rc) return rc;
 	c->texW = w;
 	c->texH = h;
 	return PT_OK;
@@ -609,6 +653,62 @@ extern "C" int pt_set_texture(pt_ctx *c, const uint8_t *rgba8, uint32_t w, uint3
 catch (const std::bad_alloc &)
 {
 	return fail(c, PT_ENOMEM, "pt_set_texture: out of host memory");
+}
+
+extern "C" int pt_set_model_texture(pt_ctx *c, uint32_t model, const uint8_t *rgba8, uint32_t w, uint32_t h) try
+{
+	if (!c) return fail(nullptr, PT_EINVAL, "null context");
+	if (!c->haveScene) return fail(c, PT_EINVAL, "pt_set_model_texture: no scene uploaded");
+	const uint32_t nModels = (uint32_t)c->modelTriCount.size();
+	if (model >= nModels) return fail(c, PT_EINVAL, "pt_set_model_texture: model %u of %u", model, nModels);
+	if ((rgba8 == nullptr) != (w == 0 || h == 0))
+		return fail(c, PT_EINVAL, "pt_set_model_texture: pixels and extent must both be given or both be empty");
+	if (w > 16384 || h > 16384) return fail(c, PT_ELIMIT, "pt_set_model_texture: %u x %u exceeds 16384 x 16384", w, h);
+	PT_HIP(c, hipSetDevice(c->device));
+	PT_HIP(c, hipStreamSynchronize(c->stream));
+	// per-Model maps replace the scene-wide one
+	hipFree(c->dTexture);
+	c->dTexture = nullptr;
+	c->texW = c->texH = 0;
+	c->modelTex.resize(nModels);
+	pt_ctx::ModelTex &t = c->modelTex[model];
+	hipFree(t.texels);
+	t = pt_ctx::ModelTex();
+	if (rgba8)
+	{
+		int rc = uploadTexels(c, "pt_set_model_texture", rgba8, w, h, &t.texels);
+		if (rc) return rc;
+		t.w = w;
+		t.h = h;
+	}
+	// the table the shading searches: one slot per Model, in primitive order
+	bool any = false;
+	std::vector<PtTexSlot> slots(nModels);
+	for (uint32_t m = 0; m < nModels; ++m)
+	{
+		slots[m].texels = c->modelTex[m].texels;
+		slots[m].w = c->modelTex[m].w;
+		slots[m].h = c->modelTex[m].h;
+		slots[m].primEnd = c->modelTriFirst[m] + c->modelTriCount[m];
+		slots[m].pad = 0;
+		any = any || c->modelTex[m].texels;
+	}
+	hipFree(c->dTexSlots);
+	c->dTexSlots = nullptr;
+	c->nTexSlots = 0;
+	if (!any)
+	{
+		freeModelTextures(c);
+		return PT_OK;
+	}
+	PT_HIP(c, hipMalloc(&c->dTexSlots, sizeof(PtTexSlot) * nModels));
+	PT_HIP(c, hipMemcpy(c->dTexSlots, slots.data(), sizeof(PtTexSlot) * nModels, hipMemcpyHostToDevice));
+	c->nTexSlots = nModels;
+	return PT_OK;
+}
+catch (const std::bad_alloc &)
+{
+	return fail(c, PT_ENOMEM, "pt_set_model_texture: out of host memory");
 }
 
 namespace

@@ -420,6 +420,15 @@ struct __attribute__((aligned(16))) PtShadeRec
 };
 static_assert(sizeof(PtShadeRec) == 96, "PtShadeRec must be 96 bytes");
 
+struct PtTexSlot  // the diffuse map of one Model
+{
+	const float4 *texels;  // nullptr: the Model has no map (hitValue = the material's diffuse colour)
+	uint32_t w, h;
+	uint32_t primEnd;  // first primitive id behind the Model's
+	uint32_t pad;
+};
+static_assert(sizeof(PtTexSlot) == 24, "PtTexSlot must be 24 bytes");
+
 struct PtSceneDev
 {
 	const PtVertex *vertices;
@@ -437,6 +446,12 @@ struct PtSceneDev
 	const float4 *texture;
 	uint32_t texW, texH;
 	uint32_t triPlanes;  // 3 (one plane per dominant ray axis) or 1 (identity only: the leaf test permutes with selects)
+	// one map per Model (pt_set_model_texture; raytrace.rchit:27 reaches every per-Model buffer through
+	// model.m[gl_InstanceCustomIndexEXT]): nTexSlots records in primitive order, slot m covers the primitives below its
+	// primEnd that no earlier slot covers; nullptr = the scene-wide map above, or none.  `texture` is then not null (the
+	// "this scene samples maps" flag that selects the gather path).
+	const PtTexSlot *texSlots;
+	uint32_t nTexSlots;
 };
 
 // Diffuse map lookup (no counterpart in the reference's shaders, which never sample textures/viking_room.png:
@@ -538,9 +553,23 @@ __device__ __forceinline__ void pt_shade_hit(const PtSceneDev &sc, uint32_t prim
 		}
 		if (sc.texture)
 		{
-			float tu = (v0[9] * bx + v1[9] * by) + v2[9] * bz, tv = (v0[10] * bx + v1[10] * by) + v2[10] * bz;
-			float3x tx = pt_sample_texture(sc.texture, sc.texW, sc.texH, tu, tv);
-			kd = { kd.x * tx.x, kd.y * tx.y, kd.z * tx.z };
+			const float4 *tex = sc.texture;
+			uint32_t tw = sc.texW, th = sc.texH;
+			if (sc.texSlots)  // (wave-uniform) one map per Model: the slot whose primitive range holds the hit
+			{
+				uint32_t m = 0;
+				while (m + 1u < sc.nTexSlots && prim >= sc.texSlots[m].primEnd) ++m;
+				const PtTexSlot slot = sc.texSlots[m];
+				tex = slot.texels;
+				tw = slot.w;
+				th = slot.h;
+			}
+			if (tex)
+			{
+				float tu = (v0[9] * bx + v1[9] * by) + v2[9] * bz, tv = (v0[10] * bx + v1[10] * by) + v2[10] * bz;
+				float3x tx = pt_sample_texture(tex, tw, th, tu, tv);
+				kd = { kd.x * tx.x, kd.y * tx.y, kd.z * tx.z };
+			}
 		}
 	}
 	pt_shade_math<kInRange>(p0, p1, p2, n0, n1, n2, bx, by, bz, seed, o, d, xf);

@@ -390,6 +390,8 @@ __global__ void __launch_bounds__(PT_WAVE) PT_PATHS_OCCUPANCY k_paths(PtPathsArg
 			fsc.matIndices = PT_COLD(sc.matIndices);
 			fsc.texW = PT_COLD(sc.texW);
 			fsc.texH = PT_COLD(sc.texH);
+			fsc.texSlots = PT_COLD(sc.texSlots);
+			fsc.nTexSlots = PT_COLD(sc.nTexSlots);
 		}
 		PT_T_MARK(PT_T_F_LOADS)
 		if ((uint32_t)lane < count)
@@ -1103,10 +1105,15 @@ __global__ void __launch_bounds__(PT_WAVE) PT_PATHS_OCCUPANCY k_paths(PtPathsArg
 			else ++leafSteps;
 		}
 		PT_T_MARK(doNode ? PT_T_NODE : PT_T_LEAF)
+		// A/B switch, off (pt_wave_traverse.h): the lanes of a quad fetch each other's node records; all 64 lanes take part
+		constexpr bool kCoop = kNodeMode == PT_NODES_GLOBAL && PT_NODE_COOP != 0;
+		PtNodeRegs pre;
+		if (kCoop && doNode) pt_node_fetch_coop(sc.nodes, cur, lane, pre);
 		if (doNode && !(cur & PT_LEAF_FLAG))
 		{
 			if (kStats) ++nodeFetches;
-			pt_node_step<kStackLds, kNodeMode>(sc, ray, tmin, best, cur, sp, sStack, lane, mySpill, a.spillStride, sNodes);
+			pt_node_step<kStackLds, kNodeMode, kCoop>(sc, ray, tmin, best, cur, sp, sStack, lane, mySpill, a.spillStride, sNodes,
+			                                          pre);
 		}
 		if (!doNode && mine)
 		{

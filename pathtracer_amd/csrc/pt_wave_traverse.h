@@ -111,10 +111,90 @@ __device__ __forceinline__ uint32_t pt_plane_record_word(const PtNode4 *nodes, u
 	return __float_as_uint((float)((w[8u + p] >> (8u * c)) & 0xFFu));
 }
 
-template <int kStackLds, int kNodeMode = PT_NODES_GLOBAL>
+
+// ------------------------------------------------------------------- cooperative node fetch ----
+// A/B switch (round 3, OFF: measured slower on every BASELINE config; profiles/r03h3_ab_coop.log).  The
+// counters of a tree-form k_paths show a busy vector L1 (viking_room: TA busy 0.70, 0.91 line look-ups per cycle and CU,
+// profiles/r03h2_viking_ta_pmc.log) and scripts/ubench/tcp_rate.hip prices its access patterns: a wave instruction whose 64
+// lanes address 64 different lines costs the TA/TCP ~44 cycles whether the lines hit or not -- the four loads of a node step
+// 177 cycles for 4 KB -- while an instruction whose lanes 4k .. 4k+3 read the four 16-byte pieces of ONE 64-byte record
+// costs 18 (hit) to 37 (miss): the texture addresser merges the lanes of a quad that fall into one line into one tag
+// look-up.  So the lanes of a quad fetch each other's nodes: instruction i has lane 4k+j load piece j of the node lane 4k+i
+// wants (address by a DPP quad broadcast of `cur`), and a 4x4 transposition inside the quad -- two butterfly stages of
+// v_cndmask_b32 with a DPP-permuted operand, 32 instructions for the 16 dwords -- hands every lane the four pieces of its
+// own node.  Same bytes, same arithmetic after it, images bit-identical.  Result: viking_room -11.5 %, teapot grid -14 %,
+// 1 M soup -19 %, 5 M soup +-0, 20 M soup +5.7 %, 100 M soup -6.4 %: the look-ups were not what those kernels wait for --
+// the 48 instructions of the exchange lengthen each wave's dependent chain by more than the cheaper fetch shortens it.
+// Every lane of the wave must call (EXEC full: a DPP operand reads the other lanes' registers).
+#ifndef PT_NODE_COOP
+#define PT_NODE_COOP 0
+#endif
+struct PtNodeRegs  // a 64-byte node record in registers
+{
+	uint4 n[4];
+};
+
+// One butterfly stage over two registers of four dwords each: lanes whose index has the stage's bit clear keep a and take
+// b from the partner lane, lanes with the bit set keep b and take a from the partner.  keepA = lanes with the bit clear.
+#define PT_QUAD_STAGE(PERM, KEEP_A_LO, KEEP_B_LO)                                                                      \
+	__device__ __forceinline__ void pt_quad_stage_##KEEP_A_LO(uint4 &a, uint4 &b)                                      \
+	{                                                                                                                  \
+		uint4 na, nb;                                                                                                  \
+		asm volatile("s_nop 1\n\t"                                                                                     \
+		             "s_mov_b32 vcc_lo, " #KEEP_A_LO "\n\ts_mov_b32 vcc_hi, " #KEEP_A_LO "\n\t"                        \
+		             "v_cndmask_b32_dpp %0, %12, %8, vcc " PERM " row_mask:0xf bank_mask:0xf\n\t"                      \
+		             "v_cndmask_b32_dpp %1, %13, %9, vcc " PERM " row_mask:0xf bank_mask:0xf\n\t"                      \
+		             "v_cndmask_b32_dpp %2, %14, %10, vcc " PERM " row_mask:0xf bank_mask:0xf\n\t"                     \
+		             "v_cndmask_b32_dpp %3, %15, %11, vcc " PERM " row_mask:0xf bank_mask:0xf\n\t"                     \
+		             "s_mov_b32 vcc_lo, " #KEEP_B_LO "\n\ts_mov_b32 vcc_hi, " #KEEP_B_LO "\n\t"                        \
+		             "v_cndmask_b32_dpp %4, %8, %12, vcc " PERM " row_mask:0xf bank_mask:0xf\n\t"                      \
+		             "v_cndmask_b32_dpp %5, %9, %13, vcc " PERM " row_mask:0xf bank_mask:0xf\n\t"                      \
+		             "v_cndmask_b32_dpp %6, %10, %14, vcc " PERM " row_mask:0xf bank_mask:0xf\n\t"                     \
+		             "v_cndmask_b32_dpp %7, %11, %15, vcc " PERM " row_mask:0xf bank_mask:0xf"                         \
+		             : "=&v"(na.x), "=&v"(na.y), "=&v"(na.z), "=&v"(na.w), "=&v"(nb.x), "=&v"(nb.y), "=&v"(nb.z),      \
+		               "=&v"(nb.w)                                                                                     \
+		             : "v"(a.x), "v"(a.y), "v"(a.z), "v"(a.w), "v"(b.x), "v"(b.y), "v"(b.z), "v"(b.w)                  \
+		             : "vcc");                                                                                         \
+		a = na;                                                                                                        \
+		b = nb;                                                                                                        \
+	}
+PT_QUAD_STAGE("quad_perm:[1,0,3,2]", 0x55555555, 0xaaaaaaaa)  // partner = lane ^ 1
+PT_QUAD_STAGE("quad_perm:[2,3,0,1]", 0x33333333, 0xcccccccc)  // partner = lane ^ 2
+#undef PT_QUAD_STAGE
+
+// R[i] of lane 4k+j holds piece j of record i of the quad  ->  R[j] of lane 4k+i holds piece j of record i
+__device__ __forceinline__ void pt_quad_transpose(uint4 (&R)[4])
+{
+	pt_quad_stage_0x55555555(R[0], R[1]);
+	pt_quad_stage_0x55555555(R[2], R[3]);
+	pt_quad_stage_0x33333333(R[0], R[2]);
+	pt_quad_stage_0x33333333(R[1], R[3]);
+}
+
+// The node `cur` of every lane that is at an inner node (bit 31 clear), fetched by the lane's quad; the other lanes get
+// whatever.  Called by ALL 64 lanes.
+__device__ __forceinline__ void pt_node_fetch_coop(const PtNode4 *nodes, uint32_t cur, int lane, PtNodeRegs &out)
+{
+	uint4 (&R)[4] = out.n;
+	const uint32_t piece = (uint32_t)lane & 3u;
+#define PT_COOP_LOAD(i)                                                                                              \
+	{                                                                                                                \
+		const uint32_t ci = (uint32_t)__builtin_amdgcn_mov_dpp((int)cur, (i) * 0x55, 0xF, 0xF, true); /* lane 4k+i's */ \
+		/* (a defined value at no cost for the quads whose lane i is not at a node: nothing reads it) */               \
+		asm volatile("" : "=v"(R[i].x), "=v"(R[i].y), "=v"(R[i].z), "=v"(R[i].w));                                   \
+		if (!(ci & PT_LEAF_FLAG)) R[i] = reinterpret_cast<const uint4 *>(nodes + ci)[piece];                         \
+	}
+	PT_COOP_LOAD(0) PT_COOP_LOAD(1) PT_COOP_LOAD(2) PT_COOP_LOAD(3)
+#undef PT_COOP_LOAD
+	pt_quad_transpose(R);
+}
+
+// kPre: `pre` holds the node record, fetched already (pt_node_fetch_coop; kNodeMode == PT_NODES_GLOBAL only)
+template <int kStackLds, int kNodeMode = PT_NODES_GLOBAL, bool kPre = false>
 __device__ __forceinline__ void pt_node_step(const PtSceneDev &sc, const PtLaneRay &ray, float tmin, const PtBest &best,
                                              uint32_t &cur, int &sp, uint32_t (*sStack)[PT_WAVE], int lane,
-                                             uint32_t *mySpill, uint32_t spillStride, const uint4 *sNodes = nullptr)
+                                             uint32_t *mySpill, uint32_t spillStride, const uint4 *sNodes = nullptr,
+                                             const PtNodeRegs &pre = PtNodeRegs())
 {
 	const float ox = ray.ox, oy = ray.oy, oz = ray.oz, ix = ray.ix, iy = ray.iy, iz = ray.iz;
 	const uint32_t kpack = ray.kpack;
@@ -166,6 +246,13 @@ __device__ __forceinline__ void pt_node_step(const PtSceneDev &sc, const PtLaneR
 			n1 = sNodes[4u * cur + 1u];
 			n2 = sNodes[4u * cur + 2u];
 			n3 = sNodes[4u * cur + 3u];
+		}
+		else if (kPre)
+		{
+			n0 = pre.n[0];
+			n1 = pre.n[1];
+			n2 = pre.n[2];
+			n3 = pre.n[3];
 		}
 		else
 		{

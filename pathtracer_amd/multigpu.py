@@ -64,6 +64,13 @@ def interleaved_columns(rank: int, world: int, width: int, block_w: int = TILE_B
 def reduce_sum_image(image_tensor, dist, dst: int = 0):
     """In-place reduce(sum) of the per-rank sum images onto `dst` (torch.distributed module passed in
     so the same code runs over nccl(=RCCL) and gloo)."""
+    if image_tensor.is_cuda and dist.get_backend() == "gloo":
+        # rehearsal on a box with fewer GPUs than ranks (bench.py --dist-backend gloo): through host memory
+        host = image_tensor.cpu()
+        dist.reduce(host, dst=dst, op=dist.ReduceOp.SUM)
+        if dist.get_rank() == dst:
+            image_tensor.copy_(host)
+        return image_tensor
     dist.reduce(image_tensor, dst=dst, op=dist.ReduceOp.SUM)
     return image_tensor
 

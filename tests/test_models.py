@@ -136,3 +136,106 @@ def test_model_errors(rt, pa):
     rt.setInstances(np.stack([xform()]), [1])
     with pytest.raises(pa.PathTracerError, match="custom_index 1"):
         rt.buildBlas(None)
+
+
+# ------------------------------------------------------------------------- one diffuse map per Model ----
+def _textured_models(pa):
+    """Two Cornell boxes with texture coordinates (different ones) and an untextured height field between them."""
+    a = pa.scenes.textured_cornell()
+    b = pa.scenes.grid_mesh(6, 6, size=2.0, amplitude=0.25)
+    c0 = pa.scenes.textured_cornell()
+    v = c0.vertices.copy()
+    v[:, 9], v[:, 10] = v[:, 10] * np.float32(0.7), v[:, 9] * np.float32(2.1)
+    c = pa.Scene(v, c0.indices, c0.materials, c0.mat_indices)
+    xf = np.stack([xform(translate=(-2.8, 0.0, 0.0)), xform(rot_y_deg=20.0, translate=(0.0, 0.3, 0.4)),
+                   xform(rot_y_deg=-30.0, scale=(0.9, 1.0, 0.9), translate=(2.8, 0.0, 0.2))])
+    return [a, b, c], xf, np.array([0, 1, 2], dtype=np.uint32)
+
+
+def test_oracle_model_textures(O, pa):
+    """Without a GPU: the same map in every slot == the scene-wide map; a Model without a map keeps its plain colours."""
+    models, xf, custom = _textured_models(pa)
+    tex = pa.scenes.random_texture(19, 11, seed=3)
+    W, H = 56, 40
+    view, proj = wide_camera(pa, W, H, eye=(0.0, 1.6, 8.0), center=(0.0, 1.0, 0.0))
+    kw = dict(frames=1, spp_per_frame=2, max_depth=5, seed=8)
+    whole, _ = O.OracleScene.from_models(models, xf, custom, texture=tex).render(view, proj, W, H, **kw)
+    slots, _ = O.OracleScene.from_models(models, xf, custom, model_textures=[tex, tex, tex]).render(view, proj, W, H, **kw)
+    assert np.array_equal(bits(whole), bits(slots))
+    plain, _ = O.OracleScene.from_models(models, xf, custom).render(view, proj, W, H, **kw)
+    none, _ = O.OracleScene.from_models(models, xf, custom, model_textures=[None, None, None]).render(view, proj, W, H, **kw)
+    assert np.array_equal(bits(plain), bits(none))
+    mixed, _ = O.OracleScene.from_models(models, xf, custom, model_textures=[tex, None, None]).render(view, proj, W, H, **kw)
+    assert not np.array_equal(bits(mixed), bits(plain)) and not np.array_equal(bits(mixed), bits(whole))
+
+
+@pytest.mark.gpu
+def test_model_textures_bit_exact(rt, pa, O):
+    """pt_set_model_texture: Model 0 and Model 2 with maps of different sizes, Model 1 without one -- against the oracle; then
+    the maps changed and removed one by one, the scene-wide map replacing them and being replaced.  (Scenes of several
+    Models are two-level scenes: the persistent pipeline.)"""
+    models, xf, custom = _textured_models(pa)
+    t0, t2 = pa.scenes.random_texture(37, 23, seed=7), pa.scenes.random_texture(16, 64, seed=11)
+    W, H = 144, 88
+    view, proj = wide_camera(pa, W, H, eye=(0.0, 1.6, 8.0), center=(0.0, 1.0, 0.0))
+    kw = dict(frames=2, spp_per_frame=3, max_depth=6, seed=5)
+    rt.uploadModels(models)
+    rt.setInstances(xf, custom)
+    rt.buildBlas(None)
+    rt.resize(W, H)
+    rt.setCamera(view, proj)
+    rt.setParams(spp_per_frame=3, max_depth=6, seed=5)
+
+    def check(model_textures=None, texture=None):
+        rt.resetFrame()
+        rt.resetStats()
+        rt.raytrace(2)
+        extra = {"model_textures": model_textures} if model_textures is not None else {"texture": texture}
+        want, rays = O.OracleScene.from_models(models, xf, custom, **extra).render(view, proj, W, H, **kw)
+        assert rt.stats().rays_total == rays
+        img = rt.readImage()
+        assert np.array_equal(bits(img), bits(want)), int((bits(img) != bits(want)).sum())
+        return img
+
+    rt.setModelTexture(0, t0)
+    rt.setModelTexture(2, t2)
+    both = check([t0, None, t2])
+    rt.setModelTexture(1, t2)
+    assert not np.array_equal(bits(check([t0, t2, t2])), bits(both))
+    rt.setModelTexture(0, None)
+    rt.setModelTexture(1, None)
+    check([None, None, t2])
+    rt.setTexture(t0)  # the scene-wide map replaces the per-Model ones ...
+    check(texture=t0)
+    rt.setModelTexture(2, t2)  # ... and is replaced by them
+    check([None, None, t2])
+    rt.setModelTexture(2, None)  # the last map gone: the plain colours
+    check(texture=None)
+    with pytest.raises(pa.PathTracerError, match="model 3 of 3"):
+        rt.setModelTexture(3, t0)
+    # a new scene drops the per-Model maps
+    rt.setModelTexture(0, t0)
+    rt.uploadModels(models)
+    rt.setInstances(xf, custom)
+    rt.buildBlas(None)
+    check(texture=None)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("pipeline", ["persistent", "fused", "split"])
+def test_model_texture_of_a_single_model_scene(rt, pa, O, pipeline):
+    """pt_upload_scene is one Model: its map through pt_set_model_texture(0, ...) == the scene-wide map, every pipeline."""
+    from pathtracer_amd.api import PT_PIPELINE_FUSED, PT_PIPELINE_PERSISTENT, PT_PIPELINE_SPLIT
+    sc, tex = pa.scenes.textured_cornell(), pa.scenes.random_texture(29, 31, seed=2)
+    W, H = 80, 64
+    view, proj = pa.reference_camera(W, H)
+    rt.setPipeline({"persistent": PT_PIPELINE_PERSISTENT, "fused": PT_PIPELINE_FUSED, "split": PT_PIPELINE_SPLIT}[pipeline])
+    rt.buildBlas(sc)
+    rt.setModelTexture(0, tex)
+    rt.resize(W, H)
+    rt.setCamera(view, proj)
+    rt.setParams(spp_per_frame=3, max_depth=6, seed=9)
+    rt.raytrace(2)
+    osc = O.OracleScene(sc.vertices, sc.indices, sc.materials, sc.mat_indices, texture=tex)
+    want, rays = osc.render(view, proj, W, H, frames=2, spp_per_frame=3, max_depth=6, seed=9)
+    assert rt.stats().rays_total == rays and np.array_equal(bits(rt.readImage()), bits(want))
