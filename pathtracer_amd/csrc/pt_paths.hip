@@ -655,18 +655,22 @@ __global__ void __launch_bounds__(PT_WAVE) PT_PATHS_OCCUPANCY k_paths(PtPathsArg
 	// two-level scenes: the bottom-level traversal of the lane's instance is finished -- back to the world ray and on with
 	// whatever the top-level traversal left on the stack
 	auto leaveInstance = [&]() {
-		ox = wox;
-		oy = woy;
-		oz = woz;
-		ix = __uint_as_float(sSave[0][lane]);
-		iy = __uint_as_float(sSave[1][lane]);
-		iz = __uint_as_float(sSave[2][lane]);
-		Sx = __uint_as_float(sSave[3][lane]);
-		Sy = __uint_as_float(sSave[4][lane]);
-		Sz = __uint_as_float(sSave[5][lane]);
-		kpack = sSave[6][lane];
-		inst = PT_NO_INSTANCE;
-		cur = pt_stack_pop<kStackLds>(sp, sStack, lane, mySpill, a.spillStride);
+		if constexpr (!kInst) return;  // (sSave has one row in the single-level instantiations)
+		else
+		{
+			ox = wox;
+			oy = woy;
+			oz = woz;
+			ix = __uint_as_float(sSave[0][lane]);
+			iy = __uint_as_float(sSave[1][lane]);
+			iz = __uint_as_float(sSave[2][lane]);
+			Sx = __uint_as_float(sSave[3][lane]);
+			Sy = __uint_as_float(sSave[4][lane]);
+			Sz = __uint_as_float(sSave[5][lane]);
+			kpack = sSave[6][lane];
+			inst = PT_NO_INSTANCE;
+			cur = pt_stack_pop<kStackLds>(sp, sStack, lane, mySpill, a.spillStride);
+		}
 	};
 
 	// top-level leaf = instance: ray into object space, o' = W2O * (o,1), d' = W2O * (d,0), each row
@@ -685,36 +689,40 @@ __global__ void __launch_bounds__(PT_WAVE) PT_PATHS_OCCUPANCY k_paths(PtPathsArg
 		L.root = a.instRoot[i];  // root of the bottom-level tree of the instance's Model
 	};
 	auto enterInstance = [&](const InstLoads &L) {
-		inst = cur & 0x0FFFFFFFu;
-		const float4 r0 = L.r0, r1 = L.r1, r2 = L.r2;
-		float3x oo, od;
-		oo.x = ((r0.x * wox + r0.y * woy) + r0.z * woz) + r0.w;
-		oo.y = ((r1.x * wox + r1.y * woy) + r1.z * woz) + r1.w;
-		oo.z = ((r2.x * wox + r2.y * woy) + r2.z * woz) + r2.w;
-		od.x = (r0.x * wdx + r0.y * wdy) + r0.z * wdz;
-		od.y = (r1.x * wdx + r1.y * wdy) + r1.z * wdz;
-		od.z = (r2.x * wdx + r2.y * wdy) + r2.z * wdz;
-		sSave[0][lane] = __float_as_uint(ix);
-		sSave[1][lane] = __float_as_uint(iy);
-		sSave[2][lane] = __float_as_uint(iz);
-		sSave[3][lane] = __float_as_uint(Sx);
-		sSave[4][lane] = __float_as_uint(Sy);
-		sSave[5][lane] = __float_as_uint(Sz);
-		sSave[6][lane] = kpack;
-		const PtLaneRay pr = pt_prepare_ray(oo, od);
-		ox = pr.ox;
-		oy = pr.oy;
-		oz = pr.oz;
-		ix = pr.ix;
-		iy = pr.iy;
-		iz = pr.iz;
-		Sx = pr.Sx;
-		Sy = pr.Sy;
-		Sz = pr.Sz;
-		kpack = pr.kpack | (kpack & 0xFFFF0000u);  // keep the depth bits
-		pt_stack_push<kStackLds>(PT_INSTANCE_END, sp, sStack, lane, mySpill, a.spillStride);
-		cur = L.root;
-		if (kStats) ++leafVisits;
+		if constexpr (!kInst) return;
+		else
+		{
+			inst = cur & 0x0FFFFFFFu;
+			const float4 r0 = L.r0, r1 = L.r1, r2 = L.r2;
+			float3x oo, od;
+			oo.x = ((r0.x * wox + r0.y * woy) + r0.z * woz) + r0.w;
+			oo.y = ((r1.x * wox + r1.y * woy) + r1.z * woz) + r1.w;
+			oo.z = ((r2.x * wox + r2.y * woy) + r2.z * woz) + r2.w;
+			od.x = (r0.x * wdx + r0.y * wdy) + r0.z * wdz;
+			od.y = (r1.x * wdx + r1.y * wdy) + r1.z * wdz;
+			od.z = (r2.x * wdx + r2.y * wdy) + r2.z * wdz;
+			sSave[0][lane] = __float_as_uint(ix);
+			sSave[1][lane] = __float_as_uint(iy);
+			sSave[2][lane] = __float_as_uint(iz);
+			sSave[3][lane] = __float_as_uint(Sx);
+			sSave[4][lane] = __float_as_uint(Sy);
+			sSave[5][lane] = __float_as_uint(Sz);
+			sSave[6][lane] = kpack;
+			const PtLaneRay pr = pt_prepare_ray(oo, od);
+			ox = pr.ox;
+			oy = pr.oy;
+			oz = pr.oz;
+			ix = pr.ix;
+			iy = pr.iy;
+			iz = pr.iz;
+			Sx = pr.Sx;
+			Sy = pr.Sy;
+			Sz = pr.Sz;
+			kpack = pr.kpack | (kpack & 0xFFFF0000u);  // keep the depth bits
+			pt_stack_push<kStackLds>(PT_INSTANCE_END, sp, sStack, lane, mySpill, a.spillStride);
+			cur = L.root;
+			if (kStats) ++leafVisits;
+		}
 	};
 	static_assert(!kInstEntryHead || kInstExitHead, "entry at the head of the iteration: the exit too");
 

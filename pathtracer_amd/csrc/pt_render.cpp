@@ -135,7 +135,7 @@ static bool reduceWithRccl(std::vector<Job> &jobs, size_t count, double *seconds
 		ncclGroupStart();
 		for (int r = 0; r < G; ++r)
 		{
-			hipSetDevice(devs[(size_t)r]);
+			if (hipSetDevice(devs[(size_t)r]) != hipSuccess) ok = false;
 			e = ncclReduce(img[(size_t)r], img[(size_t)r], count, ncclFloat, ncclSum, 0, comms[(size_t)r], nullptr);
 			if (e != ncclSuccess) ok = false;
 		}
@@ -143,8 +143,7 @@ static bool reduceWithRccl(std::vector<Job> &jobs, size_t count, double *seconds
 		if (e != ncclSuccess) ok = false;
 		for (int r = 0; r < G; ++r)
 		{
-			hipSetDevice(devs[(size_t)r]);
-			if (hipStreamSynchronize(nullptr) != hipSuccess) ok = false;
+			if (hipSetDevice(devs[(size_t)r]) != hipSuccess || hipStreamSynchronize(nullptr) != hipSuccess) ok = false;
 		}
 		if (!ok) fprintf(stderr, "-reduce rccl: ncclReduce failed: %s\n", ncclGetErrorString(e));
 	}
