@@ -282,8 +282,12 @@ def main():
             torch.cuda.set_device(device)
             dist.init_process_group("gloo")
         else:
-            torch.cuda.set_device(local_rank)
-            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+            # one GPU per rank; a launcher that narrows each rank's visibility to its own GPU (HIP_VISIBLE_DEVICES per rank)
+            # leaves that GPU as device 0
+            ndev = torch.cuda.device_count()
+            device = local_rank if local_rank < ndev else local_rank % max(1, ndev)
+            torch.cuda.set_device(device)
+            dist.init_process_group("nccl", device_id=torch.device("cuda", device))
         world = dist.get_world_size()  # as the backend sees it
         try:
             rccl = ".".join(str(x) for x in torch.cuda.nccl.version())
