@@ -27,8 +27,11 @@ def once(frames):
     t = time.perf_counter(); rt.synchronize(); dist.barrier(); torch.cuda.synchronize(); T["barrier1"] = time.perf_counter() - t
     T["total"] = time.perf_counter() - t0
     return T
+from pathtracer_amd.api import PT_PROFILE_KERNELS
+rt.setProfiling(PT_PROFILE_KERNELS)
 for rep in range(4):
     rt.resetFrame(); rt.resetStats()
     T = once(20)
-    print(" ".join(f"{k} {v*1e3:.3f} ms |" for k, v in T.items()), flush=True)
+    st = rt.stats()
+    print(" ".join(f"{k} {v*1e3:.3f} ms |" for k, v in T.items()), f"k_paths {st.extend_ms_total / max(1, st.extend_launches):.3f} ms", flush=True)
 dist.destroy_process_group()
