@@ -17,6 +17,6 @@ for set in "TA_TA_BUSY_sum TA_BUSY_avr TCP_TOTAL_CACHE_ACCESSES_sum TCP_TCC_READ
            "TCP_TAGRAM0_REQ_sum TCP_TAGRAM1_REQ_sum TCP_TAGRAM2_REQ_sum TCP_TAGRAM3_REQ_sum TA_TOTAL_WAVEFRONTS_sum TA_ADDR_STALLED_BY_TD_CYCLES_sum GRBM_GUI_ACTIVE" \
            "TCP_READ_TAGCONFLICT_STALL_CYCLES_sum TCP_TCP_LATENCY_sum TCP_TCP_TA_ADDR_STALL_CYCLES_sum TCP_TCR_TCP_STALL_CYCLES_sum GRBM_GUI_ACTIVE"; do
   i=$((i+1))
-  timeout -s KILL 120 rocprofv3 --pmc $set --output-format csv -d $OUT/pass$i -- python3 $R/bench.py --steps 4 --warmup 4 --no-cpu-baseline "$@" > $OUT/pass$i.log 2>&1 || { tail -5 $OUT/pass$i.log; echo "pass $i failed"; exit 1; }
+  timeout -s KILL 120 rocprofv3 --pmc $set --output-format csv -d $OUT/pass$i -- python3 $R/bench.py --steps 4 --warmup 4 --no-cpu-baseline --ramp-ms 0 "$@" > $OUT/pass$i.log 2>&1 || { tail -5 $OUT/pass$i.log; echo "pass $i failed"; exit 1; }
   python3 $R/scripts/pmc_summary.py $OUT/pass$i | grep -E "k_paths" | cut -c1-700
 done

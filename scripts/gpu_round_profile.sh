@@ -15,9 +15,9 @@ fi
 timeout -k 10 300 python -u bench.py > $OUT/bench_default_line.json 2> $OUT/bench_default.err || { tail $OUT/bench_default.err; exit 1; }
 cat $OUT/bench_default_line.json
 cd /tmp && export TMPDIR=/tmp
-timeout -k 10 200 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -- python3 $R/bench.py --steps 32 --warmup 16 --no-cpu-baseline > $OUT/bench_steps32_line.json 2> $OUT/stats.err || { tail $OUT/stats.err; exit 1; }
+timeout -k 10 200 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -- python3 $R/bench.py --steps 32 --warmup 16 --no-cpu-baseline --ramp-ms 0 > $OUT/bench_steps32_line.json 2> $OUT/stats.err || { tail $OUT/stats.err; exit 1; }
 cat $OUT/bench_steps32_line.json
-B="python3 $R/bench.py --steps 16 --warmup 16 --no-cpu-baseline"  # (one launch = 16 frames: every launch of the run is a full one)
+B="python3 $R/bench.py --steps 16 --warmup 16 --no-cpu-baseline --ramp-ms 0"  # (one launch = 16 frames: every launch of the run is a full one)
 timeout -s KILL 90 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_fetch -- $B > $OUT/pmc_fetch.log 2>&1 || { tail $OUT/pmc_fetch.log; exit 1; }
 timeout -s KILL 90 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/pmc_write -- $B > $OUT/pmc_write.log 2>&1 || { tail $OUT/pmc_write.log; exit 1; }
 timeout -s KILL 90 rocprofv3 --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_WAVE_CYCLES SQ_BUSY_CYCLES --output-format csv -d $OUT/pmc_sq1 -- $B > $OUT/pmc_sq1.log 2>&1 || { tail $OUT/pmc_sq1.log; exit 1; }

@@ -12,7 +12,7 @@ cd $R
 timeout -k 10 400 python -u bench.py "$@" > $OUT/bench_default_line.json 2> $OUT/bench_default.err || { tail $OUT/bench_default.err; exit 1; }
 cut -c1-600 $OUT/bench_default_line.json
 cd /tmp && export TMPDIR=/tmp
-B="python3 $R/bench.py --steps $STEPS --warmup $STEPS --no-cpu-baseline $*"
+B="python3 $R/bench.py --steps $STEPS --warmup $STEPS --no-cpu-baseline --ramp-ms 0 $*"
 timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -- $B > $OUT/bench_steps32_line.json 2> $OUT/stats.err || { tail $OUT/stats.err; exit 1; }
 timeout -s KILL 200 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_fetch -- $B > $OUT/pmc_fetch.log 2>&1 || { tail $OUT/pmc_fetch.log; exit 1; }
 timeout -s KILL 200 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/pmc_write -- $B > $OUT/pmc_write.log 2>&1 || { tail $OUT/pmc_write.log; exit 1; }
