@@ -131,3 +131,12 @@ def test_cpu_baseline_on_a_pixel_sample(monkeypatch):
     out = bench.cpu_baseline_pixels(a, sc, view, proj, tmax, budget_s=0.05)
     assert out["kind"] == "port" and out["unit"] == "Mrays/s" and out["value"] > 0 and out["cores"] >= 1
     assert "random pixels of 64x48" in out["sample"] and "no top-level structure" in out["sample"]
+
+
+def test_bench_arguments_of_round_3():
+    """--dist-backend gloo (N ranks rehearsed on fewer GPUs) and --ramp-ms (untimed clock ramp) parse; their defaults are
+    the measured path: RCCL, 150 ms."""
+    a = bench.parse([])
+    assert a.dist_backend == "nccl" and a.ramp_ms == 150.0 and a.scaling == "weak"
+    a = bench.parse(["--gpus", "4", "--dist-backend", "gloo", "--ramp-ms", "0", "--scaling", "strong"])
+    assert a.gpus == 4 and a.dist_backend == "gloo" and a.ramp_ms == 0.0 and a.scaling == "strong"
