@@ -666,21 +666,26 @@ extern "C" int pt_set_model_texture(pt_ctx *c, uint32_t model, const uint8_t *rg
 	if (w > 16384 || h > 16384) return fail(c, PT_ELIMIT, "pt_set_model_texture: %u x %u exceeds 16384 x 16384", w, h);
 	PT_HIP(c, hipSetDevice(c->device));
 	PT_HIP(c, hipStreamSynchronize(c->stream));
+	// the new map first: a failed upload leaves every map, and the table that points to them, as it was
+	pt_ctx::ModelTex fresh;
+	if (rgba8)
+	{
+		int rc = uploadTexels(c, "pt_set_model_texture", rgba8, w, h, &fresh.texels);
+		if (rc) return rc;
+		fresh.w = w;
+		fresh.h = h;
+	}
 	// per-Model maps replace the scene-wide one
 	hipFree(c->dTexture);
 	c->dTexture = nullptr;
 	c->texW = c->texH = 0;
 	c->modelTex.resize(nModels);
-	pt_ctx::ModelTex &t = c->modelTex[model];
-	hipFree(t.texels);
-	t = pt_ctx::ModelTex();
-	if (rgba8)
-	{
-		int rc = uploadTexels(c, "pt_set_model_texture", rgba8, w, h, &t.texels);
-		if (rc) return rc;
-		t.w = w;
-		t.h = h;
-	}
+	// (the table goes before the texels it points to: nothing may find a freed map through it if a step below fails)
+	hipFree(c->dTexSlots);
+	c->dTexSlots = nullptr;
+	c->nTexSlots = 0;
+	hipFree(c->modelTex[model].texels);
+	c->modelTex[model] = fresh;
 	// the table the shading searches: one slot per Model, in primitive order
 	bool any = false;
 	std::vector<PtTexSlot> slots(nModels);
@@ -693,9 +698,6 @@ extern "C" int pt_set_model_texture(pt_ctx *c, uint32_t model, const uint8_t *rg
 		slots[m].pad = 0;
 		any = any || c->modelTex[m].texels;
 	}
-	hipFree(c->dTexSlots);
-	c->dTexSlots = nullptr;
-	c->nTexSlots = 0;
 	if (!any)
 	{
 		freeModelTextures(c);
